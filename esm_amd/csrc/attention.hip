@@ -1,0 +1,311 @@
+// attention.hip — multi-head self-attention core for head_dim 64 on gfx950.
+//
+// Replaces, for one TransformerLayer, the reference's materialised attention
+// (esm/multihead_attention.py:357 bmm(q,k^T) -> :368-374 key padding fill -> :379 fp32 softmax
+// -> :387 bmm(probs,v) -> :394 merge heads) with a flash-style kernel: the [T,T] score matrix
+// never leaves the CU.  q (already scaled and rotated), k (rotated) come from the fused QKV
+// epilogue in gemm.hip as [B,H,T,64]; v comes TRANSPOSED as vt[B,H,64,Tp] with the key index
+// permuted inside groups of 16 (4-groups 1 and 2 swapped).
+//
+// attn_fwd_kernel: one workgroup = 4 waves = 128 query rows of one (batch, head); each wave
+// owns 32 query rows.  K / V^T tiles of 64 keys are staged HBM->LDS by global_load_lds_dwordx4
+// (double buffered, 128-byte rows, 16-byte chunks XOR-swizzled with (row>>1)&7 on the source
+// address and on the read, so every ds_read_b128 is bank-conflict free).
+//   S^T = K . Q^T  is computed "swapped" (MFMA A operand = K rows, B operand = Q rows): lane l
+//   then holds, for query l&31, the scores of keys (r&3)+8(r>>2)+4(l>>5) — a full softmax row
+//   lives in two lanes (l, l^32), so row max / row sum need one cross-lane exchange per tile.
+//   O^T += V^T . P^T : the P values a lane already holds are exactly its B-operand slots when
+//   the V^T A-operand uses the same (permuted) key order, so P goes registers -> MFMA with no
+//   LDS round trip and no lane permutation; O^T keeps the query in the lane (l&31) so the
+//   online-softmax rescale is a lane-local multiply.
+// Softmax is fp32 (exp2 with log2(e) folded in), P is rounded to the operand dtype for the PV
+// MFMA, accumulation is fp32.
+//
+// attn_probs_kernel: re-computes S tile by tile from q, k and the saved log-sum-exp and writes
+// normalised fp32 probabilities for need_head_weights=True / the contact head
+// (multihead_attention.py:396-403, esm2.py:119-121,132-139) with padded rows/cols zeroed.
+#include "common.h"
+#include "kernels.h"
+#include <math.h>
+
+namespace esmk {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int A_TILE = 64 * 128;  // bytes of one K (or V^T) tile: 64 rows x 128 B
+constexpr int A_STAGE = 2 * A_TILE + 256;  // K + V^T + 64 fp32 key-bias values
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
+    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
+    const float* __restrict__ key_bias, const int* __restrict__ seq_info, T* __restrict__ ctx,
+    float* __restrict__ lse, int H, int Tlen, int Tp) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * A_STAGE];
+    using V8 = typename Op<T>::v8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, lm = lane & 31;
+    const int bh = blockIdx.y;
+    const int b = bh / H, head = bh - b * H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    // padding information of this sequence (wave uniform)
+    int kv_end = Tlen;
+    bool use_mask = (Tlen & 63) != 0;
+    if (key_bias != nullptr) {
+        if (seq_info != nullptr) {
+            if (seq_info[2 * b] > 0) {  // sequence has pads: mask them, skip all-pad tail tiles
+                use_mask = true;
+                kv_end = seq_info[2 * b + 1];
+            }
+        } else {
+            use_mask = true;
+        }
+    }
+    const int ntiles = (kv_end + 63) >> 6;
+
+    const T* kb = k + (size_t)bh * Tlen * 64;
+    const T* vb = vt + (size_t)bh * 64 * Tp;
+
+    // Q fragments: Q[q0 + lm][16 ks + 8 h .. +7]
+    V8 qf[4];
+    {
+        const int qr = min(q0 + lm, Tlen - 1);
+        const T* qp = q + ((size_t)bh * Tlen + qr) * 64 + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qp + 16 * ks);
+    }
+
+    // staging sources (2 rounds of 256 lanes each for K and for V^T)
+    const T* gk[2];
+    const T* gv[2];
+    int krow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pos = j * 256 + tid;
+        const int r = pos >> 3, s = pos & 7;
+        const int c = s ^ ((r >> 1) & 7);
+        krow[j] = r;
+        gk[j] = kb + c * 8;                      // + key row * 64 (clamped per tile)
+        gv[j] = vb + (size_t)r * Tp + c * 8;     // + tile key offset
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * A_STAGE;
+        const int k0 = kt * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kr = min(k0 + krow[j], Tlen - 1);
+            glds16(gk[j] + (size_t)kr * 64, base + (j * 256 + wave * 64) * 16);
+            glds16(gv[j] + k0, base + A_TILE + (j * 256 + wave * 64) * 16);
+        }
+        if (use_mask && tid < 64) {
+            const int key = k0 + tid;
+            float bv = -INFINITY;
+            if (key < Tlen) bv = key_bias ? key_bias[(size_t)b * Tlen + key] : 0.f;
+            reinterpret_cast<float*>(base + 2 * A_TILE)[tid] = bv;
+        }
+    };
+
+    const int lrow = lm * 128;
+    const int swz = (lane >> 1) & 7;
+    int xo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xo[c] = ((2 * c + h) ^ swz) << 4;
+
+    f32x16 o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m2 = -INFINITY;  // running max in the log2 domain (score * log2 e)
+    float lsum = 0.f;      // this lane's share of the running denominator
+
+    if (ntiles > 0) stage(0, 0);
+    wait_vmcnt0();
+    __syncthreads();
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < ntiles) stage(cur ^ 1, kt + 1);
+        const char* sk = smem + cur * A_STAGE;
+        const char* sv = sk + A_TILE;
+        const float* sb = reinterpret_cast<const float*>(sk + 2 * A_TILE);
+
+        // ---- S^T = K . Q^T for 64 keys (two 32-key tiles) ---------------------------------
+        f32x16 st[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[t2][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const V8 kf = *reinterpret_cast<const V8*>(sk + t2 * 4096 + lrow + xo[ks]);
+                st[t2] = Op<T>::mma(kf, qf[ks], st[t2]);
+            }
+        }
+        // ---- key padding / tail mask (multihead_attention.py:368-374) -----------------------
+        if (use_mask) {
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(sb + t2 * 32 + 8 * g + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) st[t2][4 * g + e] += bv[e];
+                }
+        }
+        // ---- online softmax (fp32) ---------------------------------------------------------
+        float mx = st[0][0];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t2][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m2, mx * LOG2E);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m2 - m_use);
+        m2 = m_new;
+        float ps = 0.f;
+        V8 pf[4];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float p = __builtin_amdgcn_exp2f(st[t2][8 * ks + e] * LOG2E - m_use);
+                    ps += p;
+                    pf[2 * t2 + ks][e] = Op<T>::from(p);
+                }
+            }
+        lsum = lsum * alpha + ps;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        // ---- O^T += V^T . P^T ----------------------------------------------------------------
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const V8 vf = *reinterpret_cast<const V8*>(sv + d * 4096 + lrow + xo[kk]);
+                o[d] = Op<T>::mma(vf, pf[kk], o[d]);
+            }
+        wait_vmcnt0();
+        __syncthreads();
+    }
+
+    // ---- normalise and store ctx[b*T + q][head*64 + dv] ---------------------------------------
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / ltot;
+    const int qrow = q0 + lm;
+    if (qrow < Tlen) {
+        T* dst = ctx + ((size_t)b * Tlen + qrow) * ((size_t)H * 64) + head * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                typename Op<T>::v4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = Op<T>::from(o[d][4 * g + e] * inv);
+                *reinterpret_cast<typename Op<T>::v4*>(dst + d * 32 + 8 * g + 4 * h) = pk;
+            }
+        if (lse != nullptr && h == 0)
+            lse[(size_t)bh * Tlen + qrow] = m2 * (1.0f / LOG2E) + logf(ltot);
+    }
+}
+
+hipError_t launch_attention(const void* q, const void* k, const void* vt, const float* key_bias,
+                            const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
+                            int operand_dtype, hipStream_t st) {
+    if (B <= 0 || H <= 0 || T <= 0 || Tp < T || (Tp & 63)) return hipErrorInvalidValue;
+    dim3 grid((T + 127) / 128, B * H);
+    if (operand_dtype == ESMK_DT_BF16)
+        hipLaunchKernelGGL((attn_fwd_kernel<__bf16>), grid, dim3(256), 0, st, (const __bf16*)q,
+                           (const __bf16*)k, (const __bf16*)vt, key_bias, seq_info, (__bf16*)ctx, lse,
+                           H, T, Tp);
+    else
+        hipLaunchKernelGGL((attn_fwd_kernel<_Float16>), grid, dim3(256), 0, st, (const _Float16*)q,
+                           (const _Float16*)k, (const _Float16*)vt, key_bias, seq_info,
+                           (_Float16*)ctx, lse, H, T, Tp);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention probabilities for need_head_weights / contacts
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_probs_kernel(const T* __restrict__ q,
+                                                          const T* __restrict__ k,
+                                                          const float* __restrict__ lse,
+                                                          const float* __restrict__ key_bias,
+                                                          float* __restrict__ probs, int H, int Tlen,
+                                                          int layer, int Ltot) {
+    using V8 = typename Op<T>::v8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, lm = lane & 31;
+    const int bh = blockIdx.y;
+    const int b = bh / H, head = bh - b * H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    if (q0 >= Tlen) return;
+
+    V8 qf[4];
+    {
+        const int qr = min(q0 + lm, Tlen - 1);
+        const T* qp = q + ((size_t)bh * Tlen + qr) * 64 + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qp + 16 * ks);
+    }
+    // per accumulator row: log-sum-exp and query-pad flag
+    float row_lse[16];
+    float row_keep[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qr = q0 + mfma32_row(r, h);
+        const int qc = min(qr, Tlen - 1);
+        row_lse[r] = lse[(size_t)bh * Tlen + qc];
+        row_keep[r] = (key_bias != nullptr && key_bias[(size_t)b * Tlen + qc] != 0.f) ? 0.f : 1.f;
+    }
+    float* out = probs + (((size_t)b * Ltot + layer) * H + head) * (size_t)Tlen * Tlen;
+
+    for (int k0 = 0; k0 < Tlen; k0 += 32) {
+        const int key = k0 + lm;
+        const int kc = min(key, Tlen - 1);
+        const T* kp = k + ((size_t)bh * Tlen + kc) * 64 + 8 * h;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const V8 kf = *reinterpret_cast<const V8*>(kp + 16 * ks);
+            s = Op<T>::mma(qf[ks], kf, s);  // D[row = query][col = key]
+        }
+        const float kb = (key_bias != nullptr) ? key_bias[(size_t)b * Tlen + kc] : 0.f;
+        if (key < Tlen) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qr = q0 + mfma32_row(r, h);
+                if (qr < Tlen) {
+                    const float p = __expf(s[r] + kb - row_lse[r]) * row_keep[r];
+                    out[(size_t)qr * Tlen + key] = p;
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_attention_probs(const void* q, const void* k, const float* lse,
+                                  const float* key_bias, float* probs, int B, int H, int T,
+                                  int layer, int num_layers_total, int operand_dtype,
+                                  hipStream_t st) {
+    dim3 grid((T + 127) / 128, B * H);
+    if (operand_dtype == ESMK_DT_BF16)
+        hipLaunchKernelGGL((attn_probs_kernel<__bf16>), grid, dim3(256), 0, st, (const __bf16*)q,
+                           (const __bf16*)k, lse, key_bias, probs, H, T, layer, num_layers_total);
+    else
+        hipLaunchKernelGGL((attn_probs_kernel<_Float16>), grid, dim3(256), 0, st,
+                           (const _Float16*)q, (const _Float16*)k, lse, key_bias, probs, H, T, layer,
+                           num_layers_total);
+    return hipGetLastError();
+}
+
+}  // namespace esmk

@@ -1,0 +1,424 @@
+// elementwise.hip — the HBM-bound kernels of the ESM-2 forward: token statistics, embedding
+// gather with token-dropout rescale, LayerNorm, parameter conversion, RoPE tables and the
+// contact-prediction head.  All of them stream fp32 rows with 16-byte per-lane accesses; the
+// relevant roof is HBM (8 TB/s spec, ~6.3 TB/s achievable), not MFMA.
+#include "common.h"
+#include "kernels.h"
+#include <math.h>
+
+namespace esmk {
+
+// ---------------------------------------------------------------------------------------------
+// per-sequence token statistics — reference esm/model/esm2.py:82 (padding_mask), :86-92 (token
+// dropout ratio), :108-109 (mask dropped when the batch has no pad), and the key padding mask
+// of esm/multihead_attention.py:368-374 as an additive 0 / -inf row.
+//   scale[b] = 1 - n_mask/n_nonpad   (the fp32 divisor of esm2.py:92)
+//   seq_info[2b] = number of pad tokens, seq_info[2b+1] = 1 + index of the last non-pad token
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void seq_stats_kernel(const int64_t* __restrict__ tokens, int T,
+                                                         int pad_idx, int mask_idx,
+                                                         float* __restrict__ scale,
+                                                         float* __restrict__ key_bias,
+                                                         int* __restrict__ seq_info) {
+    __shared__ int s_mask[4], s_pad[4], s_last[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t* row = tokens + (size_t)b * T;
+    int n_mask = 0, n_pad = 0, last = 0;
+    for (int t = tid; t < T; t += 256) {
+        const int64_t tok = row[t];
+        const bool is_pad = tok == pad_idx;
+        n_mask += tok == mask_idx;
+        n_pad += is_pad;
+        if (!is_pad) last = t + 1;
+        key_bias[(size_t)b * T + t] = is_pad ? -INFINITY : 0.f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        n_mask += __shfl_xor(n_mask, o, 64);
+        n_pad += __shfl_xor(n_pad, o, 64);
+        last = max(last, __shfl_xor(last, o, 64));
+    }
+    if ((tid & 63) == 0) {
+        s_mask[tid >> 6] = n_mask;
+        s_pad[tid >> 6] = n_pad;
+        s_last[tid >> 6] = last;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        n_mask = s_mask[0] + s_mask[1] + s_mask[2] + s_mask[3];
+        n_pad = s_pad[0] + s_pad[1] + s_pad[2] + s_pad[3];
+        last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+        const float ratio = (float)n_mask / (float)(T - n_pad);  // esm2.py:91
+        scale[b] = 1.0f - ratio;                                   // esm2.py:92 divisor
+        seq_info[2 * b] = n_pad;
+        seq_info[2 * b + 1] = last;
+    }
+}
+
+hipError_t launch_seq_stats(const int64_t* tokens, int B, int T, int pad_idx, int mask_idx,
+                            int token_dropout, float* scale, float* key_bias, int* seq_info,
+                            hipStream_t st) {
+    (void)token_dropout;
+    hipLaunchKernelGGL(seq_stats_kernel, dim3(B), dim3(256), 0, st, tokens, T, pad_idx, mask_idx,
+                       scale, key_bias, seq_info);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// embedding — esm2.py:84 (gather), :87 (zero <mask> rows), :92 (x * 0.88 / (1 - ratio)),
+// :94-95 (zero pad rows).  One thread per 4 consecutive channels.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ tokens,
+                                                     const float* __restrict__ table,
+                                                     const float* __restrict__ scale,
+                                                     float* __restrict__ x, int T, int E4, int vocab,
+                                                     int pad_idx, int mask_idx, int token_dropout,
+                                                     size_t total4) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const size_t row = idx / E4;
+    const int c4 = (int)(idx - row * E4);
+    int64_t tok = tokens[row];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (tok >= 0 && tok < vocab) v = *reinterpret_cast<const f32x4*>(table + (size_t)tok * E4 * 4 + c4 * 4);
+    if (token_dropout) {
+        if (tok == mask_idx) {
+            v = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float den = scale[row / T];
+        const float keep = (float)(1.0 - 0.15 * 0.8);  // python: 1 - mask_ratio_train
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] * keep) / den;
+    }
+    if (tok == pad_idx) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(x + idx * 4) = v;
+}
+
+hipError_t launch_embed(const int64_t* tokens, const float* table, const float* scale, float* x,
+                        int B, int T, int E, int vocab, int pad_idx, int mask_idx,
+                        int token_dropout, hipStream_t st) {
+    const size_t total4 = (size_t)B * T * (E / 4);
+    const unsigned blocks = (unsigned)((total4 + 255) / 256);
+    hipLaunchKernelGGL(embed_kernel, dim3(blocks), dim3(256), 0, st, tokens, table, scale, x, T,
+                       E / 4, vocab, pad_idx, mask_idx, token_dropout, total4);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm — reference esm/modules.py:68-81 (ESM1bLayerNorm == torch.nn.LayerNorm, eps 1e-5,
+// biased variance, affine).  One wave per row, the row is held in registers (NCH float4 per
+// lane), two-pass mean / variance in fp32, 16-byte loads and 8/16-byte stores.
+// Algorithmic traffic per row: 4E read + 2E (operand dtype) and/or 4E (fp32) written.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         T* __restrict__ y, float* __restrict__ y32,
+                                                         int rows, int E) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int e4 = E >> 2;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * E);
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < e4) {
+            v[i] = xr[c];
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        } else {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < e4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float var = wave_sum(q) / (float)E;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < e4) {
+            const f32x4 g = g4[c], bb = b4[c];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + bb[e];
+            if (y) {
+                typename Op<T>::v4 p;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[e] = Op<T>::from(o[e]);
+                *reinterpret_cast<typename Op<T>::v4*>(y + (size_t)row * E + c * 4) = p;
+            }
+            if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)row * E + c * 4) = o;
+        }
+    }
+}
+
+template <typename T>
+static hipError_t ln_dispatch(const float* x, const float* g, const float* b, void* y, float* y32,
+                              int rows, int E, hipStream_t st) {
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    T* yt = reinterpret_cast<T*>(y);
+#define ESMK_LN(N)                                                                              \
+    hipLaunchKernelGGL((layernorm_kernel<T, N>), dim3(blocks), dim3(256), 0, st, x, g, b, yt, y32, \
+                       rows, E)
+    if (E <= 512) ESMK_LN(2);
+    else if (E <= 1280) ESMK_LN(5);
+    else if (E <= 2560) ESMK_LN(10);
+    else if (E <= 5120) ESMK_LN(20);
+    else return hipErrorInvalidValue;
+#undef ESMK_LN
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* y,
+                            float* y32, int rows, int E, int operand_dtype, hipStream_t st) {
+    if (E % 4 != 0 || rows <= 0) return hipErrorInvalidValue;
+    if (operand_dtype == ESMK_DT_BF16) return ln_dispatch<__bf16>(x, gamma, beta, y, y32, rows, E, st);
+    return ln_dispatch<_Float16>(x, gamma, beta, y, y32, rows, E, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// parameter conversion (load time only)
+// ---------------------------------------------------------------------------------------------
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void convert_kernel(const S* __restrict__ src, D* __restrict__ dst,
+                                                       size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) dst[i] = (D)(float)src[i];
+}
+
+template <typename S>
+static hipError_t convert_from(const S* src, void* dst, int dst_dtype, size_t n, hipStream_t st) {
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+    if (dst_dtype == ESMK_DT_F32)
+        hipLaunchKernelGGL((convert_kernel<S, float>), dim3(blocks), dim3(256), 0, st, src, (float*)dst, n);
+    else if (dst_dtype == ESMK_DT_F16)
+        hipLaunchKernelGGL((convert_kernel<S, _Float16>), dim3(blocks), dim3(256), 0, st, src, (_Float16*)dst, n);
+    else if (dst_dtype == ESMK_DT_BF16)
+        hipLaunchKernelGGL((convert_kernel<S, __bf16>), dim3(blocks), dim3(256), 0, st, src, (__bf16*)dst, n);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype, size_t n,
+                          hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    if (src_dtype == ESMK_DT_F32) return convert_from((const float*)src, dst, dst_dtype, n, st);
+    if (src_dtype == ESMK_DT_F16) return convert_from((const _Float16*)src, dst, dst_dtype, n, st);
+    if (src_dtype == ESMK_DT_BF16) return convert_from((const __bf16*)src, dst, dst_dtype, n, st);
+    return hipErrorInvalidValue;
+}
+
+__global__ __launch_bounds__(256) void copy_f32_kernel(const float* __restrict__ src,
+                                                        float* __restrict__ dst, size_t n4) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n4; i += stride)
+        reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+}
+
+hipError_t launch_copy_f32(const float* src, float* dst, size_t n, hipStream_t st) {
+    if (n % 4 != 0) return hipErrorInvalidValue;
+    const size_t n4 = n / 4;
+    const unsigned blocks = (unsigned)std::min<size_t>((n4 + 255) / 256, 8192);
+    hipLaunchKernelGGL(copy_f32_kernel, dim3(blocks), dim3(256), 0, st, src, dst, n4);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// RoPE tables — reference esm/rotary_embedding.py:47-61: t = arange(T) (fp32), freqs = t x
+// inv_freq (fp32 product), cos/sin in fp32.  Only the d/2 distinct columns are stored (the
+// reference duplicates them with cat(freqs, freqs)).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_table_kernel(const float* __restrict__ inv_freq,
+                                                          float* __restrict__ cs,
+                                                          float* __restrict__ sn, int T, int half) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * half) return;
+    const int t = idx / half, i = idx - t * half;
+    const float ang = (float)t * inv_freq[i];
+    cs[idx] = cosf(ang);
+    sn[idx] = sinf(ang);
+}
+
+hipError_t launch_rope_table(const float* inv_freq, float* cos, float* sin, int T, int half,
+                             hipStream_t st) {
+    const unsigned blocks = (unsigned)((T * half + 255) / 256);
+    hipLaunchKernelGGL(rope_table_kernel, dim3(blocks), dim3(256), 0, st, inv_freq, cos, sin, T, half);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// contact head — reference esm/modules.py:338-357 with symmetrize / apc (modules.py:27-41).
+//
+// With A'_c the eos-masked (modules.py:340-343) and cropped (modules.py:344-347) map of channel c,
+// S_c = A'_c + A'_c^T, r_c[i] = sum_j S_c[i][j], t_c = sum_i r_c[i]:
+//   logit[i][j] = sum_c w_c S_c[i][j] - sum_c (w_c / t_c) r_c[i] r_c[j] + b ;  out = sigmoid(logit)
+// which is apc(symmetrize(A')) fed to the 1-output regression without materialising [C,T,T]
+// copies.  Pass 1 (contact_sums_kernel) produces r_c and t_c, pass 2 (contact_out_kernel) the
+// logits; the attention tensor is read twice in total.
+// ---------------------------------------------------------------------------------------------
+constexpr int CS_COLS = 1024;  // columns handled per sweep by one block (16 per lane)
+
+__global__ __launch_bounds__(256) void contact_sums_kernel(const float* __restrict__ attn,
+                                                            const int64_t* __restrict__ tokens,
+                                                            float* __restrict__ rsum,
+                                                            float* __restrict__ tsum, int C, int T,
+                                                            int eos_idx, int bos, int eos) {
+    extern __shared__ float s_part[];  // [4][S] column partials + [S] row sums
+    const int S = T - bos - eos;
+    const int bc = blockIdx.x;
+    const int b = bc / C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* A = attn + (size_t)bc * T * T;
+    const int64_t* tok = tokens + (size_t)b * T;
+    float* s_row = s_part + 4 * S;
+
+    for (int j0 = 0; j0 < S; j0 += CS_COLS) {
+        float col[16];
+        float cm[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            col[k] = 0.f;
+            const int j = j0 + lane + 64 * k;
+            cm[k] = (j < S && !(eos && tok[j + bos] == eos_idx)) ? 1.f : 0.f;
+        }
+        for (int i = wave; i < S; i += 4) {
+            const float rm = (eos && tok[i + bos] == eos_idx) ? 0.f : 1.f;
+            const float* row = A + (size_t)(i + bos) * T + bos;
+            float rs = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int j = j0 + lane + 64 * k;
+                float v = 0.f;
+                if (j < S) v = row[j] * rm * cm[k];
+                rs += v;
+                col[k] += v;
+            }
+            rs = wave_sum(rs);
+            if (lane == 0) {
+                if (j0 == 0) s_row[i] = rs;
+                else s_row[i] += rs;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int j = j0 + lane + 64 * k;
+            if (j < S) s_part[wave * S + j] = col[k];
+        }
+    }
+    __syncthreads();
+    float tot = 0.f;
+    for (int i = threadIdx.x; i < S; i += 256) {
+        const float r = s_row[i] + ((s_part[i] + s_part[S + i]) + (s_part[2 * S + i] + s_part[3 * S + i]));
+        rsum[(size_t)bc * S + i] = r;
+        tot += r;
+    }
+    tot = wave_sum(tot);
+    __syncthreads();
+    if (lane == 0) s_part[wave] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) tsum[bc] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+__global__ __launch_bounds__(256) void contact_out_kernel(const float* __restrict__ attn,
+                                                           const int64_t* __restrict__ tokens,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ rsum,
+                                                           const float* __restrict__ tsum,
+                                                           float* __restrict__ out, int C, int T,
+                                                           int eos_idx, int bos, int eos) {
+    __shared__ float s_t[32][33];
+    const int S = T - bos - eos;
+    const int b = blockIdx.z;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int64_t* tok = tokens + (size_t)b * T;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float mi[4], mj, mjt[4], mit;
+    // masks for the direct tile (rows i0+ty+8k, col j0+tx) and the mirrored tile
+    mj = (j0 + tx < S && !(eos && tok[j0 + tx + bos] == eos_idx)) ? 1.f : 0.f;
+    mit = (i0 + tx < S && !(eos && tok[i0 + tx + bos] == eos_idx)) ? 1.f : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = i0 + ty + 8 * k, j = j0 + ty + 8 * k;
+        mi[k] = (i < S && !(eos && tok[i + bos] == eos_idx)) ? 1.f : 0.f;
+        mjt[k] = (j < S && !(eos && tok[j + bos] == eos_idx)) ? 1.f : 0.f;
+    }
+    for (int c = 0; c < C; ++c) {
+        const float* A = attn + ((size_t)b * C + c) * T * T;
+        const float wc = w[c];
+        const float wt = wc / tsum[(size_t)b * C + c];
+        const float* r = rsum + ((size_t)b * C + c) * S;
+        // mirrored tile A'[j0+ty+8k][i0+tx] -> LDS (coalesced along i), read back transposed
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + ty + 8 * k, i = i0 + tx;
+            float v = 0.f;
+            if (j < S && i < S) v = A[(size_t)(j + bos) * T + i + bos] * mjt[k] * mit;
+            s_t[ty + 8 * k][tx] = v;
+        }
+        __syncthreads();
+        const float rj = (j0 + tx < S) ? r[j0 + tx] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + ty + 8 * k, j = j0 + tx;
+            float v = 0.f;
+            if (i < S && j < S) v = A[(size_t)(i + bos) * T + j + bos] * mi[k] * mj;
+            const float sym = v + s_t[tx][ty + 8 * k];
+            const float ri = (i < S) ? r[i] : 0.f;
+            acc[k] += wc * sym - wt * ri * rj;
+        }
+    }
+    const float bb = bias ? bias[0] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = i0 + ty + 8 * k, j = j0 + tx;
+        if (i < S && j < S) {
+            const float z = acc[k] + bb;
+            out[((size_t)b * S + i) * S + j] = 1.0f / (1.0f + expf(-z));
+        }
+    }
+}
+
+hipError_t launch_contacts(const float* attn, const int64_t* tokens, const float* w,
+                           const float* b, float* scratch, float* out, int B, int C, int T,
+                           int eos_idx, int prepend_bos, int append_eos, hipStream_t st) {
+    const int bos = prepend_bos ? 1 : 0, eos = append_eos ? 1 : 0;
+    const int S = T - bos - eos;
+    if (S <= 0) return hipErrorInvalidValue;
+    float* rsum = scratch;                    // [B*C*S]
+    float* tsum = scratch + (size_t)B * C * S;  // [B*C]
+    const size_t lds = (size_t)5 * S * sizeof(float) + 64;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;  // S <= ~3270
+    hipLaunchKernelGGL(contact_sums_kernel, dim3(B * C), dim3(256), lds, st, attn, tokens, rsum,
+                       tsum, C, T, eos_idx, bos, eos);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int nt = (S + 31) / 32;
+    hipLaunchKernelGGL(contact_out_kernel, dim3(nt, nt, B), dim3(256), 0, st, attn, tokens, w, b,
+                       rsum, tsum, out, C, T, eos_idx, bos, eos);
+    return hipGetLastError();
+}
+
+}  // namespace esmk

@@ -1,0 +1,546 @@
+// engine.hip — the C ABI of libesmk.so (declared in include/esmk.h): parameter packing,
+// workspace planning and the launch sequence that replaces ESM2.forward
+// (reference esm/model/esm2.py:77-144).  Host code only; every kernel lives in gemm.hip,
+// attention.hip and elementwise.hip.
+#include "../../include/esmk.h"
+#include "kernels.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+using namespace esmk;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* what, hipError_t e) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return 1;
+}
+int fail(const std::string& msg) {
+    g_err = msg;
+    return 1;
+}
+
+#define ESMK_TRY(expr)                                  \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return fail(#expr, _e);   \
+    } while (0)
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+size_t op_size(int dt) { return dt == ESMK_DT_F32 ? 4 : 2; }
+
+struct LayerOff {
+    size_t wqkv, bqkv, wo, bo, w1, b1, w2, b2, ln1g, ln1b, ln2g, ln2b;
+};
+
+}  // namespace
+
+struct esmk_model {
+    esmk_config cfg;
+    int L, E, H, F, V, D;
+    // packed parameter image layout (byte offsets)
+    size_t embed_f32, embed_op, fin_g, fin_b, lm_w, lm_b, lm_lng, lm_lnb, lm_bias, ct_w, ct_b;
+    std::vector<LayerOff> layer;
+    size_t packed_bytes;
+    // RoPE
+    std::vector<float> inv_freq;
+    float* d_inv_freq = nullptr;
+    float* d_cos = nullptr;
+    float* d_sin = nullptr;
+    int rope_cap = 0;
+};
+
+namespace {
+
+struct Carve {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        size_t o = off;
+        off = align_up(off + bytes);
+        return o;
+    }
+};
+
+void plan_packed(esmk_model* m) {
+    const size_t os = op_size(m->cfg.operand_dtype);
+    const size_t E = m->E, F = m->F, V = m->V;
+    Carve c;
+    m->embed_f32 = c.take(V * E * 4);
+    m->embed_op = c.take(V * E * os);
+    m->fin_g = c.take(E * 4);
+    m->fin_b = c.take(E * 4);
+    m->lm_w = c.take(E * E * os);
+    m->lm_b = c.take(E * 4);
+    m->lm_lng = c.take(E * 4);
+    m->lm_lnb = c.take(E * 4);
+    m->lm_bias = c.take(V * 4);
+    m->ct_w = c.take((size_t)m->L * m->H * 4);
+    m->ct_b = c.take(4);
+    m->layer.resize(m->L);
+    for (int l = 0; l < m->L; ++l) {
+        LayerOff& o = m->layer[l];
+        o.wqkv = c.take(3 * E * E * os);
+        o.bqkv = c.take(3 * E * 4);
+        o.wo = c.take(E * E * os);
+        o.bo = c.take(E * 4);
+        o.w1 = c.take(F * E * os);
+        o.b1 = c.take(F * 4);
+        o.w2 = c.take(E * F * os);
+        o.b2 = c.take(E * 4);
+        o.ln1g = c.take(E * 4);
+        o.ln1b = c.take(E * 4);
+        o.ln2g = c.take(E * 4);
+        o.ln2b = c.take(E * 4);
+    }
+    m->packed_bytes = c.off;
+}
+
+struct Workspace {
+    size_t scale, key_bias, seq_info, x, h, big, lse, ct_scratch, total;
+    size_t q, k, vt;  // inside big
+    int Tp;
+};
+
+Workspace plan_workspace(const esmk_model* m, int B, int T, uint32_t flags) {
+    Workspace w{};
+    const size_t os = op_size(m->cfg.operand_dtype);
+    const size_t N = (size_t)B * T, E = m->E, F = m->F;
+    w.Tp = (T + 63) / 64 * 64;
+    Carve c;
+    w.scale = c.take(B * 4);
+    w.key_bias = c.take(N * 4);
+    w.seq_info = c.take((size_t)B * 2 * 4);
+    w.x = c.take(N * E * 4);
+    w.h = c.take(N * E * os);
+    const size_t qb = align_up(N * E * os);
+    const size_t vtb = align_up((size_t)B * m->H * 64 * w.Tp * os);
+    size_t big = 2 * qb + vtb;
+    if (N * F * os > big) big = N * F * os;
+    if (N * E * 4 > big) big = N * E * 4;
+    w.big = c.take(big);
+    w.q = w.big;
+    w.k = w.big + qb;
+    w.vt = w.big + 2 * qb;
+    const bool attn = flags & (ESMK_OUT_ATTN | ESMK_OUT_CONTACTS);
+    w.lse = c.take(attn ? (size_t)B * m->H * T * 4 : 0);
+    const int S = T - (m->cfg.prepend_bos ? 1 : 0) - (m->cfg.append_eos ? 1 : 0);
+    w.ct_scratch =
+        c.take((flags & ESMK_OUT_CONTACTS) ? (size_t)B * m->L * m->H * (size_t)(S > 0 ? S + 1 : 1) * 4 : 0);
+    w.total = c.off;
+    return w;
+}
+
+int ensure_rope(esmk_model* m, int T, hipStream_t st) {
+    if (m->inv_freq.empty()) return fail("esmk_set_rope_inv_freq was not called");
+    if (T <= m->rope_cap) return 0;
+    int cap = 1024;
+    while (cap < T) cap *= 2;
+    const int half = m->D / 2;
+    if (m->d_cos) {
+        ESMK_TRY(hipStreamSynchronize(st));
+        ESMK_TRY(hipFree(m->d_cos));
+        ESMK_TRY(hipFree(m->d_sin));
+        m->d_cos = m->d_sin = nullptr;
+        m->rope_cap = 0;
+    }
+    ESMK_TRY(hipMalloc(&m->d_cos, (size_t)cap * half * 4));
+    ESMK_TRY(hipMalloc(&m->d_sin, (size_t)cap * half * 4));
+    ESMK_TRY(launch_rope_table(m->d_inv_freq, m->d_cos, m->d_sin, cap, half, st));
+    m->rope_cap = cap;
+    return 0;
+}
+
+bool starts_with(const char* s, const char* p) { return strncmp(s, p, strlen(p)) == 0; }
+
+size_t numel(const int64_t* shape, int ndim) {
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    return n;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* esmk_last_error(void) { return g_err.c_str(); }
+const char* esmk_version(void) { return "esmk 0.1 (gfx950)"; }
+
+int esmk_create(const esmk_config* cfg, esmk_model** out) {
+    if (!cfg || !out) return fail("esmk_create: null argument");
+    if (cfg->num_layers <= 0 || cfg->embed_dim <= 0 || cfg->num_heads <= 0 || cfg->ffn_dim <= 0 ||
+        cfg->vocab <= 0)
+        return fail("esmk_create: non-positive dimension");
+    if (cfg->embed_dim % cfg->num_heads != 0)
+        return fail("esmk_create: embed_dim must be divisible by num_heads");
+    if (cfg->operand_dtype != ESMK_F16 && cfg->operand_dtype != ESMK_BF16)
+        return fail("esmk_create: operand_dtype must be ESMK_F16 or ESMK_BF16");
+    const int d = cfg->embed_dim / cfg->num_heads;
+    if (d != 64)
+        return fail("esmk_create: head_dim " + std::to_string(d) +
+                    " is not supported by the gfx950 attention kernels (need 64)");
+    if (cfg->embed_dim % 32 != 0 || cfg->ffn_dim % 32 != 0)
+        return fail("esmk_create: embed_dim and ffn_dim must be multiples of 32");
+    esmk_model* m = new esmk_model();
+    m->cfg = *cfg;
+    m->L = cfg->num_layers;
+    m->E = cfg->embed_dim;
+    m->H = cfg->num_heads;
+    m->F = cfg->ffn_dim;
+    m->V = cfg->vocab;
+    m->D = d;
+    plan_packed(m);
+    *out = m;
+    return 0;
+}
+
+void esmk_destroy(esmk_model* m) {
+    if (!m) return;
+    if (m->d_cos) (void)hipFree(m->d_cos);
+    if (m->d_sin) (void)hipFree(m->d_sin);
+    if (m->d_inv_freq) (void)hipFree(m->d_inv_freq);
+    delete m;
+}
+
+int esmk_set_rope_inv_freq(esmk_model* m, const float* inv_freq_host, int n) {
+    if (!m || !inv_freq_host) return fail("esmk_set_rope_inv_freq: null argument");
+    if (n != m->D / 2) return fail("esmk_set_rope_inv_freq: expected head_dim/2 values");
+    m->inv_freq.assign(inv_freq_host, inv_freq_host + n);
+    if (!m->d_inv_freq) ESMK_TRY(hipMalloc(&m->d_inv_freq, (size_t)n * 4));
+    ESMK_TRY(hipMemcpy(m->d_inv_freq, inv_freq_host, (size_t)n * 4, hipMemcpyHostToDevice));
+    m->rope_cap = 0;  // tables are rebuilt on the next forward
+    return 0;
+}
+
+int esmk_packed_bytes(const esmk_model* m, size_t* bytes) {
+    if (!m || !bytes) return fail("esmk_packed_bytes: null argument");
+    *bytes = m->packed_bytes;
+    return 0;
+}
+
+int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const char* key,
+                     const void* src_dev, int src_dtype, const int64_t* shape, int ndim,
+                     void* stream) {
+    if (!m || !packed_dev || !key || !src_dev) return fail("esmk_pack_weight: null argument");
+    if (packed_bytes < m->packed_bytes) return fail("esmk_pack_weight: packed buffer too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)packed_dev;
+    const int op = m->cfg.operand_dtype;
+    const size_t os = op_size(op);
+    const size_t E = m->E, F = m->F, V = m->V;
+    const size_t n = numel(shape, ndim);
+    auto put = [&](size_t off, int dst_dtype, size_t expect) -> int {
+        if (n != expect)
+            return fail(std::string("esmk_pack_weight: ") + key + " has " + std::to_string(n) +
+                        " elements, expected " + std::to_string(expect));
+        ESMK_TRY(launch_convert(src_dev, src_dtype, base + off, dst_dtype, n, st));
+        return 0;
+    };
+    if (!strcmp(key, "embed_tokens.weight")) {
+        if (put(m->embed_f32, ESMK_DT_F32, V * E)) return 1;
+        return put(m->embed_op, op, V * E);
+    }
+    if (!strcmp(key, "lm_head.weight")) return 0;  // tied to embed_tokens.weight (esm2.py:71-75)
+    if (!strcmp(key, "emb_layer_norm_after.weight")) return put(m->fin_g, ESMK_DT_F32, E);
+    if (!strcmp(key, "emb_layer_norm_after.bias")) return put(m->fin_b, ESMK_DT_F32, E);
+    if (!strcmp(key, "lm_head.dense.weight")) return put(m->lm_w, op, E * E);
+    if (!strcmp(key, "lm_head.dense.bias")) return put(m->lm_b, ESMK_DT_F32, E);
+    if (!strcmp(key, "lm_head.layer_norm.weight")) return put(m->lm_lng, ESMK_DT_F32, E);
+    if (!strcmp(key, "lm_head.layer_norm.bias")) return put(m->lm_lnb, ESMK_DT_F32, E);
+    if (!strcmp(key, "lm_head.bias")) return put(m->lm_bias, ESMK_DT_F32, V);
+    if (!strcmp(key, "contact_head.regression.weight"))
+        return put(m->ct_w, ESMK_DT_F32, (size_t)m->L * m->H);
+    if (!strcmp(key, "contact_head.regression.bias")) return put(m->ct_b, ESMK_DT_F32, 1);
+    if (starts_with(key, "layers.")) {
+        char* end = nullptr;
+        const long l = strtol(key + 7, &end, 10);
+        if (end == key + 7 || *end != '.' || l < 0 || l >= m->L)
+            return fail(std::string("esmk_pack_weight: bad layer index in ") + key);
+        const char* sub = end + 1;
+        const LayerOff& o = m->layer[l];
+        if (!strcmp(sub, "self_attn.q_proj.weight")) return put(o.wqkv, op, E * E);
+        if (!strcmp(sub, "self_attn.k_proj.weight")) return put(o.wqkv + E * E * os, op, E * E);
+        if (!strcmp(sub, "self_attn.v_proj.weight")) return put(o.wqkv + 2 * E * E * os, op, E * E);
+        if (!strcmp(sub, "self_attn.q_proj.bias")) return put(o.bqkv, ESMK_DT_F32, E);
+        if (!strcmp(sub, "self_attn.k_proj.bias")) return put(o.bqkv + E * 4, ESMK_DT_F32, E);
+        if (!strcmp(sub, "self_attn.v_proj.bias")) return put(o.bqkv + 2 * E * 4, ESMK_DT_F32, E);
+        if (!strcmp(sub, "self_attn.out_proj.weight")) return put(o.wo, op, E * E);
+        if (!strcmp(sub, "self_attn.out_proj.bias")) return put(o.bo, ESMK_DT_F32, E);
+        if (!strcmp(sub, "fc1.weight")) return put(o.w1, op, F * E);
+        if (!strcmp(sub, "fc1.bias")) return put(o.b1, ESMK_DT_F32, F);
+        if (!strcmp(sub, "fc2.weight")) return put(o.w2, op, E * F);
+        if (!strcmp(sub, "fc2.bias")) return put(o.b2, ESMK_DT_F32, E);
+        if (!strcmp(sub, "self_attn_layer_norm.weight")) return put(o.ln1g, ESMK_DT_F32, E);
+        if (!strcmp(sub, "self_attn_layer_norm.bias")) return put(o.ln1b, ESMK_DT_F32, E);
+        if (!strcmp(sub, "final_layer_norm.weight")) return put(o.ln2g, ESMK_DT_F32, E);
+        if (!strcmp(sub, "final_layer_norm.bias")) return put(o.ln2b, ESMK_DT_F32, E);
+        return 0;  // e.g. self_attn.rot_emb.inv_freq: rebuilt in fp32 by the engine
+    }
+    return 0;  // unknown keys are ignored
+}
+
+int esmk_workspace_bytes(const esmk_model* m, int B, int T, uint32_t out_flags, size_t* bytes) {
+    if (!m || !bytes) return fail("esmk_workspace_bytes: null argument");
+    if (B <= 0 || T <= 0) return fail("esmk_workspace_bytes: B and T must be positive");
+    *bytes = plan_workspace(m, B, T, out_flags).total;
+    return 0;
+}
+
+int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_dev, int B, int T,
+                 const int32_t* repr_layers, int n_repr, void* const* repr_out_dev,
+                 uint32_t out_flags, void* logits_out_dev, void* attn_out_dev,
+                 void* contacts_out_dev, void* workspace_dev, size_t workspace_bytes,
+                 void* stream) {
+    if (!m || !packed_dev || !tokens_dev || !workspace_dev) return fail("esmk_forward: null argument");
+    if (B <= 0 || T <= 0) return fail("esmk_forward: B and T must be positive");
+    if (n_repr > 0 && (!repr_layers || !repr_out_dev)) return fail("esmk_forward: null repr arrays");
+    const bool want_logits = out_flags & ESMK_OUT_LOGITS;
+    const bool want_contacts = out_flags & ESMK_OUT_CONTACTS;
+    const bool want_attn = (out_flags & ESMK_OUT_ATTN) || want_contacts;
+    if (want_logits && !logits_out_dev) return fail("esmk_forward: logits buffer missing");
+    if (want_attn && !attn_out_dev) return fail("esmk_forward: attention buffer missing");
+    if (want_contacts && !contacts_out_dev) return fail("esmk_forward: contacts buffer missing");
+    for (int i = 0; i < n_repr; ++i)
+        if (repr_layers[i] < 0 || repr_layers[i] > m->L || !repr_out_dev[i])
+            return fail("esmk_forward: bad repr layer request");
+    const Workspace w = plan_workspace(m, B, T, out_flags);
+    if (workspace_bytes < w.total) return fail("esmk_forward: workspace too small");
+
+    hipStream_t st = (hipStream_t)stream;
+    const int op = m->cfg.operand_dtype;
+    const size_t os = op_size(op);
+    const int N = B * T, E = m->E, F = m->F, H = m->H, L = m->L;
+    char* ws = (char*)workspace_dev;
+    const char* pk = (const char*)packed_dev;
+    float* scale = (float*)(ws + w.scale);
+    float* key_bias = (float*)(ws + w.key_bias);
+    int* seq_info = (int*)(ws + w.seq_info);
+    float* x = (float*)(ws + w.x);
+    void* h = ws + w.h;
+    void* q = ws + w.q;
+    void* k = ws + w.k;
+    void* vt = ws + w.vt;
+    void* ffn = ws + w.big;
+    float* g32 = (float*)(ws + w.big);
+    float* lse = want_attn ? (float*)(ws + w.lse) : nullptr;
+
+    if (ensure_rope(m, T, st)) return 1;
+
+    auto repr_copy = [&](int layer, const float* src) -> int {
+        for (int i = 0; i < n_repr; ++i)
+            if (repr_layers[i] == layer)
+                ESMK_TRY(launch_copy_f32(src, (float*)repr_out_dev[i], (size_t)N * E, st));
+        return 0;
+    };
+    auto wants_repr = [&](int layer) {
+        for (int i = 0; i < n_repr; ++i)
+            if (repr_layers[i] == layer) return true;
+        return false;
+    };
+
+    // esm2.py:82-95
+    ESMK_TRY(launch_seq_stats(tokens_dev, B, T, m->cfg.pad_idx, m->cfg.mask_idx,
+                              m->cfg.token_dropout, scale, key_bias, seq_info, st));
+    ESMK_TRY(launch_embed(tokens_dev, (const float*)(pk + m->embed_f32), scale, x, B, T, E, m->V,
+                          m->cfg.pad_idx, m->cfg.mask_idx, m->cfg.token_dropout, st));
+    if (repr_copy(0, x)) return 1;  // esm2.py:99-100
+
+    GemmArgs g;
+    for (int l = 0; l < L; ++l) {  // esm2.py:111-121 -> modules.py:120-142
+        const LayerOff& o = m->layer[l];
+        // keys in [T,Tp) of V^T get probability exactly 0 but must be finite; the region is
+        // shared with the FFN intermediate, so it is cleared every layer (odd T only).
+        if (w.Tp != T) ESMK_TRY(hipMemsetAsync(vt, 0, (size_t)B * H * 64 * w.Tp * os, st));
+        ESMK_TRY(launch_layernorm(x, (const float*)(pk + o.ln1g), (const float*)(pk + o.ln1b), h,
+                                  nullptr, N, E, op, st));
+        g = GemmArgs();
+        g.A = h;
+        g.W = pk + o.wqkv;
+        g.bias = (const float*)(pk + o.bqkv);
+        g.M = N;
+        g.N = 3 * E;
+        g.K = E;
+        g.q = q;
+        g.k = k;
+        g.vt = vt;
+        g.cos = m->d_cos;
+        g.sin = m->d_sin;
+        g.T = T;
+        g.H = H;
+        g.E = E;
+        g.Tp = w.Tp;
+        g.scaling = 1.0f / sqrtf((float)m->D);
+        ESMK_TRY(launch_gemm(g, EPI_QKV_ROPE, op, st));
+        ESMK_TRY(launch_attention(q, k, vt, key_bias, seq_info, h, lse, B, H, T, w.Tp, op, st));
+        if (want_attn)
+            ESMK_TRY(launch_attention_probs(q, k, lse, key_bias, (float*)attn_out_dev, B, H, T, l, L,
+                                            op, st));
+        g = GemmArgs();
+        g.A = h;
+        g.W = pk + o.wo;
+        g.bias = (const float*)(pk + o.bo);
+        g.out = x;
+        g.M = N;
+        g.N = E;
+        g.K = E;
+        ESMK_TRY(launch_gemm(g, EPI_RESID_F32, op, st));
+        ESMK_TRY(launch_layernorm(x, (const float*)(pk + o.ln2g), (const float*)(pk + o.ln2b), h,
+                                  nullptr, N, E, op, st));
+        g = GemmArgs();
+        g.A = h;
+        g.W = pk + o.w1;
+        g.bias = (const float*)(pk + o.b1);
+        g.out = ffn;
+        g.M = N;
+        g.N = F;
+        g.K = E;
+        ESMK_TRY(launch_gemm(g, EPI_GELU_T, op, st));
+        g = GemmArgs();
+        g.A = ffn;
+        g.W = pk + o.w2;
+        g.bias = (const float*)(pk + o.b2);
+        g.out = x;
+        g.M = N;
+        g.N = E;
+        g.K = F;
+        ESMK_TRY(launch_gemm(g, EPI_RESID_F32, op, st));
+        if (l + 1 < L && repr_copy(l + 1, x)) return 1;  // esm2.py:117-118
+    }
+
+    // esm2.py:123-128: final LayerNorm; representation L is the normalised stream
+    float* rep_last = nullptr;
+    for (int i = 0; i < n_repr; ++i)
+        if (repr_layers[i] == L) {
+            rep_last = (float*)repr_out_dev[i];
+            break;
+        }
+    if (want_logits || wants_repr(L)) {
+        ESMK_TRY(launch_layernorm(x, (const float*)(pk + m->fin_g), (const float*)(pk + m->fin_b),
+                                  want_logits ? h : nullptr, rep_last, N, E, op, st));
+        for (int i = 0; i < n_repr; ++i)  // duplicates of layer L, if any
+            if (repr_layers[i] == L && repr_out_dev[i] != rep_last)
+                ESMK_TRY(launch_copy_f32(rep_last, (float*)repr_out_dev[i], (size_t)N * E, st));
+    }
+    if (want_logits) {  // modules.py:308-314
+        g = GemmArgs();
+        g.A = h;
+        g.W = pk + m->lm_w;
+        g.bias = (const float*)(pk + m->lm_b);
+        g.out = g32;
+        g.M = N;
+        g.N = E;
+        g.K = E;
+        ESMK_TRY(launch_gemm(g, EPI_GELU_F32, op, st));
+        ESMK_TRY(launch_layernorm(g32, (const float*)(pk + m->lm_lng), (const float*)(pk + m->lm_lnb),
+                                  h, nullptr, N, E, op, st));
+        g = GemmArgs();
+        g.A = h;
+        g.W = pk + m->embed_op;
+        g.bias = (const float*)(pk + m->lm_bias);
+        g.out = logits_out_dev;
+        g.M = N;
+        g.N = m->V;
+        g.K = E;
+        ESMK_TRY(launch_gemm(g, EPI_STORE_F32, op, st));
+    }
+    if (want_contacts)  // esm2.py:140-142 -> modules.py:338-357
+        ESMK_TRY(launch_contacts((const float*)attn_out_dev, tokens_dev, (const float*)(pk + m->ct_w),
+                                 (const float*)(pk + m->ct_b), (float*)(ws + w.ct_scratch),
+                                 (float*)contacts_out_dev, B, L * H, T, m->cfg.eos_idx,
+                                 m->cfg.prepend_bos, m->cfg.append_eos, st));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// single-kernel entry points
+// ---------------------------------------------------------------------------------------------
+int esmk_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                      void* y_dev, float* y32_dev, int rows, int E, int operand_dtype,
+                      void* stream) {
+    ESMK_TRY(launch_layernorm(x_dev, gamma_dev, beta_dev, y_dev, y32_dev, rows, E, operand_dtype,
+                              (hipStream_t)stream));
+    return 0;
+}
+
+int esmk_op_linear(const void* a_dev, const void* w_dev, const float* bias_dev, void* out_dev,
+                   int M, int N, int K, int epilogue, int operand_dtype, void* stream) {
+    if (epilogue < 0 || epilogue > 4) return fail("esmk_op_linear: bad epilogue");
+    GemmArgs g;
+    g.A = a_dev;
+    g.W = w_dev;
+    g.bias = bias_dev;
+    g.out = out_dev;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    if (operand_dtype & 0x100) {  // test hook: force the generic 64x64 kernel
+        g.force_generic = 1;
+        operand_dtype &= 0xff;
+    }
+    ESMK_TRY(launch_gemm(g, epilogue, operand_dtype, (hipStream_t)stream));
+    return 0;
+}
+
+int esmk_op_qkv_rope(esmk_model* m, const void* a_dev, const void* wqkv_dev,
+                     const float* bias_dev, void* q_out, void* k_out, void* vt_out, int B, int T,
+                     void* stream) {
+    if (!m) return fail("esmk_op_qkv_rope: null model");
+    hipStream_t st = (hipStream_t)stream;
+    if (ensure_rope(m, T, st)) return 1;
+    const int Tp = (T + 63) / 64 * 64;
+    if (Tp != T)
+        ESMK_TRY(hipMemsetAsync(vt_out, 0, (size_t)B * m->H * 64 * Tp * op_size(m->cfg.operand_dtype),
+                                st));
+    GemmArgs g;
+    g.A = a_dev;
+    g.W = wqkv_dev;
+    g.bias = bias_dev;
+    g.M = B * T;
+    g.N = 3 * m->E;
+    g.K = m->E;
+    g.q = q_out;
+    g.k = k_out;
+    g.vt = vt_out;
+    g.cos = m->d_cos;
+    g.sin = m->d_sin;
+    g.T = T;
+    g.H = m->H;
+    g.E = m->E;
+    g.Tp = Tp;
+    g.scaling = 1.0f / sqrtf((float)m->D);
+    ESMK_TRY(launch_gemm(g, EPI_QKV_ROPE, m->cfg.operand_dtype, st));
+    return 0;
+}
+
+int esmk_op_attention(const void* q_dev, const void* k_dev, const void* vt_dev,
+                      const float* key_bias_dev, void* ctx_out, float* lse_out, int B, int H,
+                      int T, int operand_dtype, void* stream) {
+    const int Tp = (T + 63) / 64 * 64;
+    ESMK_TRY(launch_attention(q_dev, k_dev, vt_dev, key_bias_dev, nullptr, ctx_out, lse_out, B, H, T,
+                              Tp, operand_dtype, (hipStream_t)stream));
+    return 0;
+}
+
+int esmk_op_attention_probs(const void* q_dev, const void* k_dev, const float* lse_dev,
+                            const float* key_bias_dev, float* probs_out, int B, int H, int T,
+                            int layer, int num_layers_total, int operand_dtype, void* stream) {
+    ESMK_TRY(launch_attention_probs(q_dev, k_dev, lse_dev, key_bias_dev, probs_out, B, H, T, layer,
+                                    num_layers_total, operand_dtype, (hipStream_t)stream));
+    return 0;
+}
+
+int esmk_op_contacts(const float* attn_dev, const int64_t* tokens_dev, const float* w_dev,
+                     const float* b_dev, float* scratch_dev, float* out_dev, int B, int C, int T,
+                     int eos_idx, int prepend_bos, int append_eos, void* stream) {
+    ESMK_TRY(launch_contacts(attn_dev, tokens_dev, w_dev, b_dev, scratch_dev, out_dev, B, C, T,
+                             eos_idx, prepend_bos, append_eos, (hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

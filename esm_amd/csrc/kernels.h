@@ -1,0 +1,73 @@
+// kernels.h — host-side declarations of the kernel launchers (internal to libesmk.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace esmk {
+
+enum { ESMK_DT_F32 = 0, ESMK_DT_F16 = 1, ESMK_DT_BF16 = 2 };
+
+enum {
+    EPI_STORE_T = 0,    // out[M,N] operand dtype = acc + bias
+    EPI_STORE_F32 = 1,  // out[M,N] fp32          = acc + bias
+    EPI_GELU_T = 2,     // out operand dtype      = gelu(acc + bias)
+    EPI_GELU_F32 = 3,   // out fp32               = gelu(acc + bias)
+    EPI_RESID_F32 = 4,  // out fp32              += acc + bias
+    EPI_QKV_ROPE = 5    // fused q/k/v projection epilogue (head_dim 64 only)
+};
+
+struct GemmArgs {
+    const void* A = nullptr;      // [M,K] operand dtype
+    const void* W = nullptr;      // [N,K] operand dtype
+    const float* bias = nullptr;  // [N] or null
+    void* out = nullptr;
+    int M = 0, N = 0, K = 0;
+    int force_generic = 0;
+    // EPI_QKV_ROPE only
+    void* q = nullptr;   // [B,H,T,64]
+    void* k = nullptr;   // [B,H,T,64]
+    void* vt = nullptr;  // [B,H,64,Tp]
+    const float* cos = nullptr;  // [T,32]
+    const float* sin = nullptr;  // [T,32]
+    int T = 0, H = 0, E = 0, Tp = 0;
+    float scaling = 1.f;
+};
+
+hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st);
+
+// ---- elementwise.hip -------------------------------------------------------------------
+// per-sequence statistics of the token matrix (esm2.py:82,86-92): scale[b] for token dropout,
+// key_bias[b,t] = 0 / -inf (multihead_attention.py:368-374), seq_info[2b] = #pads (esm2.py:108-109),
+// seq_info[2b+1] = 1 + index of the last non-pad token
+hipError_t launch_seq_stats(const int64_t* tokens, int B, int T, int pad_idx, int mask_idx,
+                            int token_dropout, float* scale, float* key_bias, int* seq_info,
+                            hipStream_t st);
+// embedding gather + token-dropout rescale + pad zeroing (esm2.py:84-95)
+hipError_t launch_embed(const int64_t* tokens, const float* table, const float* scale, float* x,
+                        int B, int T, int E, int vocab, int pad_idx, int mask_idx,
+                        int token_dropout, hipStream_t st);
+// LayerNorm(E, eps=1e-5) (modules.py:68-81): fp32 rows -> operand-dtype and/or fp32 rows
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* y,
+                            float* y32, int rows, int E, int operand_dtype, hipStream_t st);
+// dtype conversion of a parameter tensor into the packed image
+hipError_t launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype, size_t n,
+                          hipStream_t st);
+// RoPE tables cos/sin[t][i] = cos/sin(t * inv_freq[i]) (rotary_embedding.py:47-61), fp32
+hipError_t launch_rope_table(const float* inv_freq, float* cos, float* sin, int T, int half,
+                             hipStream_t st);
+hipError_t launch_copy_f32(const float* src, float* dst, size_t n, hipStream_t st);
+// contact head (modules.py:27-41,338-357)
+hipError_t launch_contacts(const float* attn, const int64_t* tokens, const float* w,
+                           const float* b, float* scratch, float* out, int B, int C, int T,
+                           int eos_idx, int prepend_bos, int append_eos, hipStream_t st);
+
+// ---- attention.hip ---------------------------------------------------------------------
+hipError_t launch_attention(const void* q, const void* k, const void* vt, const float* key_bias,
+                            const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
+                            int operand_dtype, hipStream_t st);
+hipError_t launch_attention_probs(const void* q, const void* k, const float* lse,
+                                  const float* key_bias, float* probs, int B, int H, int T,
+                                  int layer, int num_layers_total, int operand_dtype,
+                                  hipStream_t st);
+
+}  // namespace esmk

@@ -1,0 +1,145 @@
+/*
+ * esmk.h — C ABI of libesmk.so, the MI355X (gfx950) ESM-2 forward engine.
+ *
+ * The reference (facebookresearch/esm) has no FFI: its boundary for this path is the Python
+ * call  ESM2.forward(tokens, repr_layers, need_head_weights, return_contacts)
+ * (reference esm/model/esm2.py:77-147).  libesmk.so sits directly under that call: the Python
+ * class esm_amd.esm2.ESM2 keeps the reference's nn.Module surface and hands raw device
+ * pointers to esmk_forward().  Every entry point below names the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer named *_dev is a device pointer owned by the caller (a torch tensor);
+ *     the library borrows it for the duration of the call and allocates nothing persistent
+ *     except the small RoPE cos/sin table (freed in esmk_destroy);
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - return value 0 = ok, non-zero = error, message via esmk_last_error() (thread local);
+ *   - a handle is bound to the device that was current at esmk_create() and is not re-entrant.
+ */
+#ifndef ESMK_H
+#define ESMK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types for esmk_bind_weight / operand_dtype */
+enum { ESMK_F32 = 0, ESMK_F16 = 1, ESMK_BF16 = 2 };
+
+/* esmk_forward out_flags */
+enum {
+    ESMK_OUT_LOGITS = 1u,   /* logits [B,T,V] fp32                       (esm2.py:129)      */
+    ESMK_OUT_ATTN = 2u,     /* attentions [B,L,H,T,T] fp32               (esm2.py:132-139)  */
+    ESMK_OUT_CONTACTS = 4u  /* contacts [B,T-2,T-2] fp32                 (esm2.py:140-142)  */
+};
+
+typedef struct esmk_model esmk_model;
+
+/* Model hyper-parameters: the constructor arguments of ESM2 (esm/model/esm2.py:15-38) plus the
+ * alphabet ids it copies from the Alphabet (esm/data.py:116-120). */
+typedef struct esmk_config {
+    int32_t num_layers;      /* L                                                        */
+    int32_t embed_dim;       /* E                                                        */
+    int32_t num_heads;       /* H, head_dim d = E/H                                      */
+    int32_t ffn_dim;         /* 4E for ESM-2 (esm2.py:53)                                */
+    int32_t vocab;           /* len(alphabet) = 33                                       */
+    int32_t pad_idx, mask_idx, cls_idx, eos_idx;
+    int32_t token_dropout;   /* esm2.py:86-92                                            */
+    int32_t prepend_bos, append_eos; /* contact head crop (modules.py:338-347)           */
+    int32_t operand_dtype;   /* ESMK_F16 or ESMK_BF16: MFMA operand type; accumulation,
+                                residual stream, LayerNorm, softmax are always fp32     */
+} esmk_config;
+
+const char* esmk_last_error(void);
+const char* esmk_version(void);
+
+/* Replaces ESM2.__init__/_init_submodules (esm2.py:15-75): records dimensions only. */
+int esmk_create(const esmk_config* cfg, esmk_model** out);
+void esmk_destroy(esmk_model* m);
+
+/* RoPE inverse frequencies, fp32 host array of head_dim/2 values, exactly the buffer
+ * RotaryEmbedding.__init__ builds (esm/rotary_embedding.py:40-41). The cos/sin tables
+ * (rotary_embedding.py:47-61) are built on the device in fp32 from it. */
+int esmk_set_rope_inv_freq(esmk_model* m, const float* inv_freq_host, int n);
+
+/* Bytes of the packed parameter image (operand-dtype matrices + fp32 vectors). */
+int esmk_packed_bytes(const esmk_model* m, size_t* bytes);
+
+/* Replaces nn.Module.load_state_dict for the engine copy: converts ONE state-dict tensor
+ * (key names as in esm2.py state_dict, e.g. "layers.3.self_attn.q_proj.weight") from its
+ * device buffer into the packed image.  q/k/v projections are concatenated to one [3E,E]
+ * operand; the tied lm_head.weight (esm2.py:71-75) is taken from embed_tokens.weight.
+ * Unknown keys (e.g. "...rot_emb.inv_freq") return 0 and are ignored. */
+int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const char* key,
+                     const void* src_dev, int src_dtype, const int64_t* shape, int ndim,
+                     void* stream);
+
+/* Workspace bytes for one forward of [B,T] tokens with the given outputs. */
+int esmk_workspace_bytes(const esmk_model* m, int B, int T, uint32_t out_flags, size_t* bytes);
+
+/* Replaces ESM2.forward (esm/model/esm2.py:77-144) — embedding + token dropout, the
+ * TransformerLayer loop (esm/modules.py:120-142 -> esm/multihead_attention.py:159-405,
+ * esm/rotary_embedding.py:63-69), final LayerNorm, RobertaLMHead (modules.py:308-314),
+ * attention maps and ContactPredictionHead (modules.py:338-357).
+ *   tokens_dev     int64 [B,T]
+ *   repr_layers    host array of n_repr layer indices in [0,L]; repr_out_dev[i] fp32 [B,T,E]
+ *   logits_out_dev fp32 [B,T,V]            (required iff ESMK_OUT_LOGITS)
+ *   attn_out_dev   fp32 [B,L,H,T,T]        (required iff ESMK_OUT_ATTN or ESMK_OUT_CONTACTS)
+ *   contacts_out_dev fp32 [B,T-2,T-2]      (required iff ESMK_OUT_CONTACTS)
+ */
+int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_dev, int B, int T,
+                 const int32_t* repr_layers, int n_repr, void* const* repr_out_dev,
+                 uint32_t out_flags, void* logits_out_dev, void* attn_out_dev,
+                 void* contacts_out_dev, void* workspace_dev, size_t workspace_bytes,
+                 void* stream);
+
+/* ---- single-kernel entry points (used by the parity tests and micro-benchmarks) -------- */
+
+/* ESM1bLayerNorm == torch.nn.LayerNorm(E, eps=1e-5) (esm/modules.py:68-81).
+ * x fp32 [rows,E] -> y (operand dtype) [rows,E] and/or y32 fp32 [rows,E] (either may be NULL). */
+int esmk_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                      void* y_dev, float* y32_dev, int rows, int E, int operand_dtype,
+                      void* stream);
+
+/* nn.Linear: C[M,N] = A[M,K] . W[N,K]^T + bias, epilogue selected by `epilogue`:
+ *   0 plain -> out operand dtype [M,N]           1 plain -> out fp32 [M,N]
+ *   2 gelu (modules.py:17-24) -> operand dtype   3 gelu -> fp32
+ *   4 residual: out fp32 [M,N] += result         (modules.py:134,140)
+ * A, W operand dtype; bias fp32 (may be NULL). */
+int esmk_op_linear(const void* a_dev, const void* w_dev, const float* bias_dev, void* out_dev,
+                   int M, int N, int K, int epilogue, int operand_dtype, void* stream);
+
+/* Fused q/k/v projection + scaling + rotary + head split (multihead_attention.py:256-284,
+ * :354-355; rotary_embedding.py:11-20).  a [B*T,E]; wqkv [3E,E]; bias [3E];
+ * q_out,k_out [B,H,T,64]; vt_out [B,H,64,Tp] (V transposed, keys permuted in groups of 16,
+ * Tp = T rounded up to 64; see attention.hip). */
+int esmk_op_qkv_rope(esmk_model* m, const void* a_dev, const void* wqkv_dev,
+                     const float* bias_dev, void* q_out, void* k_out, void* vt_out, int B, int T,
+                     void* stream);
+
+/* softmax(q k^T + key_bias) v  (multihead_attention.py:357-394), flash style.
+ * key_bias fp32 [B,T] (0 or -inf, NULL = no padding); ctx_out [B*T, H*64] operand dtype;
+ * lse_out fp32 [B,H,T] or NULL. */
+int esmk_op_attention(const void* q_dev, const void* k_dev, const void* vt_dev,
+                      const float* key_bias_dev, void* ctx_out, float* lse_out, int B, int H,
+                      int T, int operand_dtype, void* stream);
+
+/* Per-head attention probabilities (multihead_attention.py:396-403, esm2.py:132-139):
+ * probs_out fp32 [B, Ltot, H, T, T] slice `layer`, rows/cols of padded tokens zeroed. */
+int esmk_op_attention_probs(const void* q_dev, const void* k_dev, const float* lse_dev,
+                            const float* key_bias_dev, float* probs_out, int B, int H, int T,
+                            int layer, int num_layers_total, int operand_dtype, void* stream);
+
+/* ContactPredictionHead.forward (modules.py:338-357) incl. symmetrize/apc (modules.py:27-41).
+ * attn fp32 [B,C=L*H,T,T]; w fp32 [C]; b fp32 [1]; scratch fp32 >= B*C*(T+1) floats;
+ * out fp32 [B,T-2,T-2] (crop follows prepend_bos/append_eos). */
+int esmk_op_contacts(const float* attn_dev, const int64_t* tokens_dev, const float* w_dev,
+                     const float* b_dev, float* scratch_dev, float* out_dev, int B, int C, int T,
+                     int eos_idx, int prepend_bos, int append_eos, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESMK_H */

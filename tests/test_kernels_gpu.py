@@ -1,0 +1,195 @@
+"""Single-kernel parity tests on the MI355X: every HIP kernel of libesmk.so, called through the
+C ABI (esm_amd.ops -> ctypes), against a plain PyTorch fp32 reference of the same op evaluated on
+the SAME operand values (inputs are rounded to the operand dtype first, so the tolerance only has
+to cover fp32 accumulation order and the final rounding of the output)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float16, torch.bfloat16]
+
+
+def _eps(dt):
+    return 2.0 ** -11 if dt == torch.float16 else 2.0 ** -8
+
+
+def _gelu(x):
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from esm_amd import ops as _ops
+
+    return _ops
+
+
+@pytest.mark.parametrize("E,rows", [(1280, 1001), (128, 7), (2560, 64), (320, 33), (5120, 5)])
+@pytest.mark.parametrize("dt", DT)
+def test_layernorm(ops, E, rows, dt):
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(rows, E, device="cuda", generator=g) * 3 + 0.5
+    gamma = 1 + 0.1 * torch.randn(E, device="cuda", generator=g)
+    beta = 0.1 * torch.randn(E, device="cuda", generator=g)
+    y, y32 = ops.layernorm(x, gamma, beta, dt, want_op=True, want_f32=True)
+    ref = torch.nn.functional.layer_norm(x, (E,), gamma, beta, 1e-5)
+    assert (y32 - ref).abs().max().item() < 2e-5
+    assert (y.float() - ref).abs().max().item() <= _eps(dt) * ref.abs().max().item() * 1.01 + 1e-6
+
+
+@pytest.mark.parametrize(
+    "M,N,K,generic",
+    [
+        (300, 384, 256, False),   # M and N tails of the 256x256 tile
+        (1024, 1280, 1280, False),
+        (512, 1280, 5120, False),
+        (64, 128, 64, False),
+        (77, 33, 320, False),     # K % 64 != 0 and N % 4 != 0 -> generic kernel
+        (130, 200, 96, True),
+        (256, 256, 128, True),
+    ],
+)
+@pytest.mark.parametrize("dt", DT)
+def test_linear_epilogues(ops, M, N, K, generic, dt):
+    from esm_amd import _native as nat
+
+    g = torch.Generator(device="cuda").manual_seed(2)
+    a = torch.randn(M, K, device="cuda", generator=g).to(dt)
+    # asymmetric, non-uniform weights so that a transposed / permuted tile cannot pass
+    w = (torch.randn(N, K, device="cuda", generator=g) * torch.linspace(0.5, 1.5, N, device="cuda")[:, None]).to(dt)
+    bias = torch.randn(N, device="cuda", generator=g)
+    ref = a.float() @ w.float().t() + bias
+    tol = 3e-5 * math.sqrt(K) * 4 + 1e-5
+
+    out = ops.linear(a, w, bias, nat.EPI_STORE_F32, force_generic=generic)
+    assert (out - ref).abs().max().item() < tol
+    out = ops.linear(a, w, None, nat.EPI_STORE_F32, force_generic=generic)
+    assert (out - (ref - bias)).abs().max().item() < tol
+    out = ops.linear(a, w, bias, nat.EPI_STORE_T, force_generic=generic)
+    assert (out.float() - ref).abs().max().item() < tol + _eps(dt) * ref.abs().max().item()
+    out = ops.linear(a, w, bias, nat.EPI_GELU_F32, force_generic=generic)
+    assert (out - _gelu(ref)).abs().max().item() < tol
+    out = ops.linear(a, w, bias, nat.EPI_GELU_T, force_generic=generic)
+    assert (out.float() - _gelu(ref)).abs().max().item() < tol + _eps(dt) * ref.abs().max().item()
+    resid = torch.randn(M, N, device="cuda", generator=g)
+    acc = resid.clone()
+    ops.linear(a, w, bias, nat.EPI_RESID_F32, out=acc, force_generic=generic)
+    assert (acc - (resid + ref)).abs().max().item() < tol
+
+
+def _rope_ref(x, inv_freq):
+    # reference esm/rotary_embedding.py:11-20,47-61 restated for [B,H,T,d]
+    T = x.shape[-2]
+    t = torch.arange(T, device=x.device).float()
+    freqs = torch.einsum("i,j->ij", t, inv_freq.to(x.device))
+    emb = torch.cat((freqs, freqs), dim=-1)
+    cos, sin = emb.cos(), emb.sin()
+    x1, x2 = x.chunk(2, dim=-1)
+    return x * cos + torch.cat((-x2, x1), dim=-1) * sin
+
+
+@pytest.mark.parametrize("E,H,B,T", [(128, 2, 3, 100), (1280, 20, 2, 256), (256, 4, 1, 1024), (128, 2, 2, 5)])
+@pytest.mark.parametrize("dt", DT)
+def test_qkv_rope(ops, E, H, B, T, dt):
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn(B * T, E, device="cuda", generator=g).to(dt)
+    w = (torch.randn(3 * E, E, device="cuda", generator=g) / math.sqrt(E)).to(dt)
+    bias = 0.1 * torch.randn(3 * E, device="cuda", generator=g)
+    hnd = ops.QkvHandle(E, H, dt)
+    q, k, vt = hnd(a, w, bias, B, T)
+    y = a.float() @ w.float().t() + bias  # [B*T, 3E]
+    yq, yk, yv = [t.reshape(B, T, H, 64).permute(0, 2, 1, 3) for t in y.split(E, dim=1)]
+    yq = _rope_ref(yq * 64 ** -0.5, hnd.inv_freq)
+    yk = _rope_ref(yk, hnd.inv_freq)
+    tol = 1e-4 + _eps(dt) * max(yq.abs().max().item(), yk.abs().max().item(), yv.abs().max().item())
+    assert (q.float() - yq).abs().max().item() < tol
+    assert (k.float() - yk).abs().max().item() < tol
+    ref_vt = ops.make_vt(yv.contiguous())
+    assert vt.shape == ref_vt.shape
+    assert (vt.float() - ref_vt).abs().max().item() < tol
+
+
+def _attn_ref(q, k, v, key_bias):
+    s = q.float() @ k.float().transpose(-1, -2)
+    if key_bias is not None:
+        s = s + key_bias[:, None, None, :]
+    p = torch.softmax(s, dim=-1)
+    return p, p @ v.float()
+
+
+@pytest.mark.parametrize("B,H,T,pad", [(2, 3, 1024, 0), (2, 2, 100, 0), (3, 2, 257, 60), (1, 1, 64, 0), (2, 2, 12, 5)])
+@pytest.mark.parametrize("dt", DT)
+def test_attention(ops, B, H, T, pad, dt):
+    g = torch.Generator(device="cuda").manual_seed(4)
+    # scores with a usable dynamic range (row max of softmax well above uniform)
+    q = (torch.randn(B, H, T, 64, device="cuda", generator=g) * 0.6).to(dt)
+    k = (torch.randn(B, H, T, 64, device="cuda", generator=g) * 0.6).to(dt)
+    v = torch.randn(B, H, T, 64, device="cuda", generator=g).to(dt)
+    key_bias = None
+    if pad:
+        key_bias = torch.zeros(B, T, device="cuda")
+        key_bias[0, T - pad:] = float("-inf")  # trailing pads on sequence 0
+        if B > 1:
+            key_bias[1, 3] = float("-inf")      # an interior pad on sequence 1
+    vt = ops.make_vt(v)
+    ctx, lse = ops.attention(q, k, vt, key_bias, want_lse=True)
+    p_ref, o_ref = _attn_ref(q, k, v, key_bias)
+    o_ref = o_ref.permute(0, 2, 1, 3).reshape(B * T, H * 64)
+    err = (ctx.float() - o_ref).abs().max().item()
+    assert err < 4 * _eps(dt) * max(1.0, o_ref.abs().max().item()), err
+    s = q.float() @ k.float().transpose(-1, -2)
+    if key_bias is not None:
+        s = s + key_bias[:, None, None, :]
+    lse_ref = torch.logsumexp(s, dim=-1)
+    assert (lse - lse_ref).abs().max().item() < 1e-3
+    probs = ops.attention_probs(q, k, lse, key_bias)
+    if key_bias is not None:
+        keep = (key_bias == 0).float()
+        p_ref = p_ref * keep[:, None, :, None] * keep[:, None, None, :]
+    assert (probs[:, 0] - p_ref).abs().max().item() < 2e-3 * p_ref.max().item() + 1e-6
+    if key_bias is not None:
+        assert (probs[:, 0][p_ref == 0] == 0).all()  # exact zeros on padded rows / cols
+
+
+def test_attention_rescale_spike(ops):
+    """A key that dominates one query late in the sweep forces the online-softmax rescale path."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, H, T = 1, 1, 512
+    q = (torch.randn(B, H, T, 64, device="cuda", generator=g) * 0.3)
+    k = (torch.randn(B, H, T, 64, device="cuda", generator=g) * 0.3)
+    k[0, 0, 400] = q[0, 0, 17] * 40.0
+    k[0, 0, 130] = q[0, 0, 300] * 25.0
+    q, k = q.half(), k.half()
+    v = torch.randn(B, H, T, 64, device="cuda", generator=g).half()
+    ctx = ops.attention(q, k, ops.make_vt(v))
+    _, o_ref = _attn_ref(q, k, v, None)
+    o_ref = o_ref.permute(0, 2, 1, 3).reshape(B * T, H * 64)
+    assert (ctx.float() - o_ref).abs().max().item() < 4 * _eps(torch.float16) * max(1.0, o_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,L,H,T", [(2, 2, 3, 40), (1, 1, 2, 130)])
+def test_contacts(ops, B, L, H, T):
+    g = torch.Generator(device="cuda").manual_seed(6)
+    attn = torch.rand(B, L, H, T, T, device="cuda", generator=g)
+    attn = attn / attn.sum(-1, keepdim=True)
+    tokens = torch.randint(4, 24, (B, T), device="cuda", generator=g)
+    tokens[:, 0] = 0
+    tokens[0, T - 1] = 2
+    if B > 1:  # shorter second sequence: eos inside, pads after
+        tokens[1, T - 10] = 2
+        tokens[1, T - 9:] = 1
+    w = torch.randn(1, L * H, device="cuda", generator=g)
+    b = torch.randn(1, device="cuda", generator=g)
+    out = ops.contacts(attn, tokens, w, b)
+    # reference: esm/modules.py:338-357 + symmetrize/apc (modules.py:27-41), restated
+    em = tokens.ne(2).float()
+    a = attn * (em[:, :, None] * em[:, None, :])[:, None, None]
+    a = a[..., :-1, :-1][..., 1:, 1:].reshape(B, L * H, T - 2, T - 2)
+    s = a + a.transpose(-1, -2)
+    a1, a2, a12 = s.sum(-1, keepdim=True), s.sum(-2, keepdim=True), s.sum((-1, -2), keepdim=True)
+    n = s - a1 * a2 / a12
+    ref = torch.sigmoid((n.permute(0, 2, 3, 1) @ w.t()).squeeze(-1) + b)
+    assert (out - ref).abs().max().item() < 2e-5
