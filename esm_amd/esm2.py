@@ -1,0 +1,277 @@
+"""ESM-2 as a drop-in ``nn.Module`` whose forward pass runs in libesmk.so on the MI355X.
+
+The class keeps the public surface of the reference ``esm.model.esm2.ESM2`` (reference
+esm/model/esm2.py:15-147): constructor arguments, attribute names, state-dict key names
+(``layers.{i}.self_attn.q_proj.weight`` ...), ``forward(tokens, repr_layers, need_head_weights,
+return_contacts)`` and ``predict_contacts``.  The sub-modules below are *parameter containers*
+with the reference's names; no layer math is done in Python/torch — ``forward`` hands raw device
+pointers to ``esmk_forward`` (include/esmk.h).  There is no CPU path: CPU tensors raise.
+"""
+import ctypes
+import os
+from typing import Union
+
+import torch
+import torch.nn as nn
+
+from .alphabet import Alphabet
+
+
+class _Container(nn.Module):
+    """Holds parameters under the reference's names; calling it is an error by design."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError(
+            f"{type(self).__name__} is a parameter container of the MI355X engine; "
+            "the layer math runs inside ESM2.forward (libesmk.so), not per sub-module"
+        )
+
+
+class RotaryEmbedding(_Container):
+    """Carries the ``inv_freq`` buffer of reference esm/rotary_embedding.py:40-41."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        inv_freq = 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim))
+        self.register_buffer("inv_freq", inv_freq)
+
+
+class MultiheadAttention(_Container):
+    def __init__(self, embed_dim, num_heads):
+        super().__init__()
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.head_dim = embed_dim // num_heads
+        assert self.head_dim * num_heads == embed_dim, "embed_dim must be divisible by num_heads"
+        self.scaling = self.head_dim ** -0.5
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.q_proj = nn.Linear(embed_dim, embed_dim)
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self.rot_emb = RotaryEmbedding(self.head_dim)
+
+
+class TransformerLayer(_Container):
+    def __init__(self, embed_dim, ffn_embed_dim, attention_heads):
+        super().__init__()
+        self.embed_dim, self.ffn_embed_dim, self.attention_heads = embed_dim, ffn_embed_dim, attention_heads
+        self.self_attn = MultiheadAttention(embed_dim, attention_heads)
+        self.self_attn_layer_norm = nn.LayerNorm(embed_dim)
+        self.fc1 = nn.Linear(embed_dim, ffn_embed_dim)
+        self.fc2 = nn.Linear(ffn_embed_dim, embed_dim)
+        self.final_layer_norm = nn.LayerNorm(embed_dim)
+
+
+class RobertaLMHead(_Container):
+    def __init__(self, embed_dim, output_dim, weight):
+        super().__init__()
+        self.dense = nn.Linear(embed_dim, embed_dim)
+        self.layer_norm = nn.LayerNorm(embed_dim)
+        self.weight = weight  # tied to embed_tokens.weight
+        self.bias = nn.Parameter(torch.zeros(output_dim))
+
+
+class ContactPredictionHead(_Container):
+    def __init__(self, in_features, prepend_bos, append_eos, bias=True, eos_idx=None):
+        super().__init__()
+        self.in_features, self.prepend_bos, self.append_eos = in_features, prepend_bos, append_eos
+        if append_eos and eos_idx is None:
+            raise ValueError("Using an alphabet with eos token, but no eos token was passed in.")
+        self.eos_idx = eos_idx
+        self.regression = nn.Linear(in_features, 1, bias)
+
+
+def _operand_dtype_for(param_dtype):
+    env = os.environ.get("ESM_AMD_OPERAND", "").lower()
+    if env in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    if env in ("f16", "fp16", "float16", "half"):
+        return torch.float16
+    # fp16 operands keep the 33-layer stack within 1e-3 of the fp32 reference (bf16: ~5e-3)
+    return torch.bfloat16 if param_dtype == torch.bfloat16 else torch.float16
+
+
+class _Engine:
+    """One esmk_model handle + packed parameter image + workspace for one (device, dtype)."""
+
+    def __init__(self, model: "ESM2", device, operand_dtype):
+        from . import _native as N
+
+        self.N = N
+        self.device = device
+        self.operand_dtype = operand_dtype
+        cfg = N.EsmkConfig(
+            model.num_layers, model.embed_dim, model.attention_heads, 4 * model.embed_dim,
+            model.alphabet_size, model.padding_idx, model.mask_idx, model.cls_idx, model.eos_idx,
+            int(bool(model.token_dropout)), int(bool(model.prepend_bos)), int(bool(model.append_eos)),
+            N.dtype_code(operand_dtype),
+        )
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            N.check(N.lib.esmk_create(ctypes.byref(cfg), ctypes.byref(self.handle)))
+            d = model.embed_dim // model.attention_heads
+            inv = (1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))).tolist()
+            arr = (ctypes.c_float * len(inv))(*inv)
+            N.check(N.lib.esmk_set_rope_inv_freq(self.handle, arr, len(inv)))
+            nbytes = ctypes.c_size_t()
+            N.check(N.lib.esmk_packed_bytes(self.handle, ctypes.byref(nbytes)))
+            self.packed = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+        self.fingerprint = None
+        self.workspace = None
+        self._named = None
+
+    def close(self):
+        if self.handle:
+            self.N.lib.esmk_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync_weights(self, model):
+        """Re-pack the parameter image when any parameter storage or version changed
+        (``.cuda()``, ``.half()``, ``load_state_dict``, in-place edits)."""
+        N = self.N
+        if self._named is None:  # Parameter objects persist across .cuda()/.half()/load_state_dict
+            self._named = [(k, t) for k, t in model.state_dict(keep_vars=True).items()
+                           if k != "lm_head.weight" and not k.endswith("inv_freq")]
+        named = self._named
+        fp = tuple((t.data_ptr(), t._version, t.dtype) for _, t in named)
+        if fp == self.fingerprint:
+            return
+        stream = N.cur_stream()
+        for key, t in named:
+            t = t.detach()
+            if not t.is_contiguous():
+                t = t.contiguous()
+            shape = (ctypes.c_int64 * t.dim())(*t.shape)
+            N.check(N.lib.esmk_pack_weight(self.handle, N.ptr(self.packed), self.packed.numel(),
+                                           key.encode(), N.ptr(t), N.dtype_code(t.dtype), shape, t.dim(),
+                                           stream))
+        self.fingerprint = fp
+
+    def workspace_for(self, B, T, flags):
+        N = self.N
+        need = ctypes.c_size_t()
+        N.check(N.lib.esmk_workspace_bytes(self.handle, B, T, flags, ctypes.byref(need)))
+        if self.workspace is None or self.workspace.numel() < need.value:
+            self.workspace = None
+            self.workspace = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        return self.workspace
+
+
+class ESM2(nn.Module):
+    def __init__(
+        self,
+        num_layers: int = 33,
+        embed_dim: int = 1280,
+        attention_heads: int = 20,
+        alphabet: Union[Alphabet, str] = "ESM-1b",
+        token_dropout: bool = True,
+    ):
+        super().__init__()
+        self.num_layers = num_layers
+        self.embed_dim = embed_dim
+        self.attention_heads = attention_heads
+        if not isinstance(alphabet, Alphabet):
+            alphabet = Alphabet.from_architecture(alphabet)
+        self.alphabet = alphabet
+        self.alphabet_size = len(alphabet)
+        self.padding_idx = alphabet.padding_idx
+        self.mask_idx = alphabet.mask_idx
+        self.cls_idx = alphabet.cls_idx
+        self.eos_idx = alphabet.eos_idx
+        self.prepend_bos = alphabet.prepend_bos
+        self.append_eos = alphabet.append_eos
+        self.token_dropout = token_dropout
+        self._engine = None
+        self._init_submodules()
+
+    def _init_submodules(self):
+        self.embed_scale = 1
+        self.embed_tokens = nn.Embedding(self.alphabet_size, self.embed_dim, padding_idx=self.padding_idx)
+        self.layers = nn.ModuleList(
+            [TransformerLayer(self.embed_dim, 4 * self.embed_dim, self.attention_heads) for _ in range(self.num_layers)]
+        )
+        self.contact_head = ContactPredictionHead(
+            self.num_layers * self.attention_heads, self.prepend_bos, self.append_eos, eos_idx=self.eos_idx
+        )
+        self.emb_layer_norm_after = nn.LayerNorm(self.embed_dim)
+        self.lm_head = RobertaLMHead(self.embed_dim, self.alphabet_size, self.embed_tokens.weight)
+
+    # ------------------------------------------------------------------------------------------
+    def _get_engine(self, device):
+        pdt = self.embed_tokens.weight.dtype
+        odt = _operand_dtype_for(pdt)
+        eng = self._engine
+        if eng is None or eng.device != device or eng.operand_dtype != odt:
+            if eng is not None:
+                eng.close()
+            eng = _Engine(self, device, odt)
+            object.__setattr__(self, "_engine", eng)
+        return eng
+
+    def forward(self, tokens, repr_layers=[], need_head_weights=False, return_contacts=False):
+        if return_contacts:
+            need_head_weights = True
+        assert tokens.ndim == 2
+        if not tokens.is_cuda:
+            raise RuntimeError(
+                "esm_amd.ESM2 runs only on an MI355X (ROCm) device: move the model and tokens to "
+                "'cuda' first; the engine has no CPU fallback"
+            )
+        w = self.embed_tokens.weight
+        if w.device != tokens.device:
+            raise RuntimeError(f"model parameters are on {w.device} but tokens on {tokens.device}")
+        from . import _native as N
+
+        dev = tokens.device
+        B, T = tokens.shape
+        L, E, H, V = self.num_layers, self.embed_dim, self.attention_heads, self.alphabet_size
+        repr_set = sorted({int(i) for i in repr_layers if 0 <= int(i) <= L})
+        with torch.cuda.device(dev):
+            eng = self._get_engine(dev)
+            eng.sync_weights(self)
+            tok = tokens.to(torch.int64).contiguous()
+            flags = N.OUT_LOGITS
+            f32 = dict(dtype=torch.float32, device=dev)
+            logits = torch.empty((B, T, V), **f32)
+            reps = [torch.empty((B, T, E), **f32) for _ in repr_set]
+            attn = contacts = None
+            if need_head_weights:
+                flags |= N.OUT_ATTN
+                attn = torch.empty((B, L, H, T, T), **f32)
+            if return_contacts:
+                flags |= N.OUT_CONTACTS
+                S = T - int(self.prepend_bos) - int(self.append_eos)
+                contacts = torch.empty((B, S, S), **f32)
+            ws = eng.workspace_for(B, T, flags)
+            layers_arr = (ctypes.c_int32 * max(1, len(repr_set)))(*repr_set)
+            outs_arr = (ctypes.c_void_p * max(1, len(repr_set)))(*[r.data_ptr() for r in reps])
+            N.check(N.lib.esmk_forward(
+                eng.handle, N.ptr(eng.packed), N.ptr(tok), B, T, layers_arr, len(repr_set), outs_arr,
+                flags, N.ptr(logits), N.ptr(attn), N.ptr(contacts), N.ptr(ws), ws.numel(), N.cur_stream()))
+        out_dt = w.dtype
+        cast = (lambda t: t) if out_dt == torch.float32 else (lambda t: t.to(out_dt))
+        result = {"logits": cast(logits), "representations": {l: cast(r) for l, r in zip(repr_set, reps)}}
+        if need_head_weights:
+            result["attentions"] = cast(attn)
+            if return_contacts:
+                result["contacts"] = cast(contacts)
+        return result
+
+    def refresh_engine(self):
+        """Drop the engine state (call after replacing Parameter objects or sub-modules)."""
+        if self._engine is not None:
+            self._engine.close()
+        object.__setattr__(self, "_engine", None)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engine"] = None  # the native handle is rebuilt lazily
+        return state
+
+    def predict_contacts(self, tokens):
+        return self(tokens, return_contacts=True)["contacts"]

@@ -1,0 +1,116 @@
+"""Deterministic synthetic ESM-2 parameters and checkpoints.
+
+No pretrained weights exist offline (no network on either box), so parity tests and the benchmark
+use seeded random parameters: every tensor is drawn from its own generator, seeded by the CRC32 of
+its state-dict key XOR a global seed, independent of any module constructor.  The q/k projection
+weights are scaled by ``qk_gain`` (default 2) so that softmax rows are clearly non-uniform —
+with small random weights attention is ~1/T everywhere and RoPE / masking / head-layout bugs are
+numerically muted — while the stack stays non-chaotic end to end.
+"""
+import argparse
+import os
+import zlib
+
+import torch
+
+ESM2_DIMS = {
+    # name: (layers, embed_dim, heads)                                   
+    "esm2_t6_8M_UR50D": (6, 320, 20),
+    "esm2_t12_35M_UR50D": (12, 480, 20),
+    "esm2_t30_150M_UR50D": (30, 640, 20),
+    "esm2_t33_650M_UR50D": (33, 1280, 20),
+    "esm2_t36_3B_UR50D": (36, 2560, 40),
+    "esm2_t48_15B_UR50D": (48, 5120, 40),
+}
+
+
+def esm2_param_shapes(num_layers, embed_dim, heads, vocab=33):
+    """State-dict keys and shapes of ESM2 (reference esm/model/esm2.py:40-75)."""
+    E, F = embed_dim, 4 * embed_dim
+    shapes = {"embed_tokens.weight": (vocab, E)}
+    for i in range(num_layers):
+        p = f"layers.{i}."
+        for proj in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            shapes[p + f"self_attn.{proj}.weight"] = (E, E)
+            shapes[p + f"self_attn.{proj}.bias"] = (E,)
+        shapes[p + "self_attn.rot_emb.inv_freq"] = (E // heads // 2,)
+        shapes[p + "self_attn_layer_norm.weight"] = (E,)
+        shapes[p + "self_attn_layer_norm.bias"] = (E,)
+        shapes[p + "fc1.weight"] = (F, E)
+        shapes[p + "fc1.bias"] = (F,)
+        shapes[p + "fc2.weight"] = (E, F)
+        shapes[p + "fc2.bias"] = (E,)
+        shapes[p + "final_layer_norm.weight"] = (E,)
+        shapes[p + "final_layer_norm.bias"] = (E,)
+    shapes["contact_head.regression.weight"] = (1, num_layers * heads)
+    shapes["contact_head.regression.bias"] = (1,)
+    shapes["emb_layer_norm_after.weight"] = (E,)
+    shapes["emb_layer_norm_after.bias"] = (E,)
+    shapes["lm_head.weight"] = (vocab, E)
+    shapes["lm_head.bias"] = (vocab,)
+    shapes["lm_head.dense.weight"] = (E, E)
+    shapes["lm_head.dense.bias"] = (E,)
+    shapes["lm_head.layer_norm.weight"] = (E,)
+    shapes["lm_head.layer_norm.bias"] = (E,)
+    return shapes
+
+
+def _draw(key, shape, seed, std, mean=0.0, device="cpu"):
+    g = torch.Generator(device=device)
+    g.manual_seed((zlib.crc32(key.encode()) ^ seed) & 0x7FFFFFFF)
+    return torch.randn(shape, generator=g, device=device, dtype=torch.float32) * std + mean
+
+
+def synth_esm2_state_dict(num_layers, embed_dim, heads, seed=0, qk_gain=2.0, device="cpu", vocab=33):
+    """fp32 state dict with the reference's key names (tied lm_head.weight included)."""
+    sd = {}
+    d = embed_dim // heads
+    for key, shape in esm2_param_shapes(num_layers, embed_dim, heads, vocab).items():
+        if key.endswith("inv_freq"):
+            sd[key] = (1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))).to(device)
+        elif key == "lm_head.weight":
+            continue
+        elif key == "embed_tokens.weight":
+            sd[key] = _draw(key, shape, seed, 0.25, device=device)
+        elif key.startswith("contact_head.regression.weight"):
+            sd[key] = _draw(key, shape, seed, 4.0, device=device)
+        elif key.startswith("contact_head.regression.bias"):
+            sd[key] = _draw(key, shape, seed, 0.5, mean=-1.0, device=device)
+        elif "layer_norm" in key and key.endswith(".weight"):
+            sd[key] = _draw(key, shape, seed, 0.02, mean=1.0, device=device)
+        elif len(shape) == 2:
+            # std 0.02 at fan-in 1280, scaled with fan-in^-1/2 so that activation statistics (and
+            # the sharpness of the attention) do not depend on the model width
+            gain = qk_gain if (".q_proj." in key or ".k_proj." in key) else 1.0
+            sd[key] = _draw(key, shape, seed, 0.02 * (1280.0 / shape[1]) ** 0.5 * gain, device=device)
+        else:
+            sd[key] = _draw(key, shape, seed, 0.02, device=device)
+    sd["lm_head.weight"] = sd["embed_tokens.weight"]
+    return sd
+
+
+def synth_tokens(batch, length, seed=1, device="cpu"):
+    """BASELINE synthetic batch: <cls> + `length` uniform ids in 4..23 + <eos> (SURVEY §8 d)."""
+    g = torch.Generator()
+    g.manual_seed(seed)
+    toks = torch.randint(4, 24, (batch, length + 2), generator=g, dtype=torch.int64)
+    toks[:, 0] = 0
+    toks[:, -1] = 2
+    return toks.to(device)
+
+
+def write_esm2_checkpoint(directory, name, num_layers, embed_dim, heads, seed=0, qk_gain=2.0, token_dropout=True):
+    """Write ``<name>.pt`` + ``<name>-contact-regression.pt`` in the reference's ESM-2 checkpoint
+    format (SURVEY.md Appendix A / reference esm/pretrained.py:67-77,164-188)."""
+    os.makedirs(directory, exist_ok=True)
+    sd = synth_esm2_state_dict(num_layers, embed_dim, heads, seed, qk_gain)
+    regression = {k: v for k, v in sd.items() if k.startswith("contact_head.")}
+    body = {"encoder.sentence_encoder." + k: v for k, v in sd.items() if not k.startswith("contact_head.")}
+    cfg = argparse.Namespace(
+        encoder_layers=num_layers, encoder_embed_dim=embed_dim, encoder_attention_heads=heads,
+        token_dropout=token_dropout,
+    )
+    path = os.path.join(directory, name + ".pt")
+    torch.save({"cfg": {"model": cfg}, "model": body}, path)
+    torch.save({"model": regression}, os.path.join(directory, name + "-contact-regression.pt"))
+    return path

@@ -1,0 +1,149 @@
+"""ORACLE — test infrastructure only.  NOT part of the product.
+
+A plain-PyTorch fp32 CPU restatement of the reference's ESM-2 forward pass, written from the
+behavioural spec (SURVEY.md §8 a-1 ... a-14) with the reference location of every step cited.
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import
+this module, and only as the *checker*; the shipped path (esm_amd.ESM2 -> libesmk.so) never does.
+
+Pinning: the reference publishes no numeric fixtures for ESM-2 (SURVEY.md §8 c), so this restatement
+is pinned against the reference ITSELF: ``tests/golden/make_golden.py`` imports
+``/root/reference/esm`` in the build container, runs ``esm.ESM2`` on seeded synthetic weights and
+stores its outputs under ``tests/golden/``; ``tests/test_oracle.py`` checks this file against those
+fixtures to <= 2e-5.
+
+It works on a state dict (reference key names) — it does not use esm_amd's modules.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def gelu(x):
+    # reference esm/modules.py:17-24 (exact erf form)
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def layer_norm(x, w, b):
+    # reference esm/modules.py:68-81: ESM1bLayerNorm == torch.nn.LayerNorm(E), eps 1e-5
+    return F.layer_norm(x, (x.shape[-1],), w, b, 1e-5)
+
+
+def rope_tables(T, head_dim, device=None):
+    # reference esm/rotary_embedding.py:40-41 (inv_freq) and :47-61 (cos/sin of t x inv_freq,
+    # the d/2 frequencies duplicated)
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, head_dim, 2, device=device).float() / head_dim))
+    t = torch.arange(T, device=device).float()
+    freqs = torch.outer(t, inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos(), emb.sin()
+
+
+def apply_rope(x, cos, sin):
+    # reference esm/rotary_embedding.py:11-20; x [..., T, d]
+    half = x.shape[-1] // 2
+    rot = torch.cat((-x[..., half:], x[..., :half]), dim=-1)
+    return x * cos + rot * sin
+
+
+def attention_layer(sd, prefix, x, heads, pad_mask, need_weights):
+    """Self-attention of one TransformerLayer on x [B,T,E] (reference works on [T,B,E], the math
+    is layout independent).  reference esm/multihead_attention.py:256-261 (projections, q scaling),
+    :280-284 (head split), :354-355 (rotary), :357 (scores), :368-374 (key padding -inf),
+    :379-380 (fp32 softmax), :387-395 (PV, merge, out_proj)."""
+    B, T, E = x.shape
+    d = E // heads
+    p = prefix + "self_attn."
+    q = F.linear(x, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"]) * (d ** -0.5)
+    k = F.linear(x, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"])
+    v = F.linear(x, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"])
+    q, k, v = (t.view(B, T, heads, d).transpose(1, 2) for t in (q, k, v))  # [B,H,T,d]
+    cos, sin = rope_tables(T, d, x.device)
+    q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
+    scores = q @ k.transpose(-1, -2)  # [B,H,T,T]
+    if pad_mask is not None:
+        scores = scores.masked_fill(pad_mask[:, None, None, :], float("-inf"))
+    probs = torch.softmax(scores.float(), dim=-1)
+    ctx = (probs @ v).transpose(1, 2).reshape(B, T, E)
+    out = F.linear(ctx, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
+    return out, (probs if need_weights else None)
+
+
+def transformer_layer(sd, i, x, heads, pad_mask, need_weights):
+    # reference esm/modules.py:120-142 (pre-LN residual blocks)
+    p = f"layers.{i}."
+    h = layer_norm(x, sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"])
+    a, probs = attention_layer(sd, p, h, heads, pad_mask, need_weights)
+    x = x + a
+    h = layer_norm(x, sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"])
+    h = gelu(F.linear(h, sd[p + "fc1.weight"], sd[p + "fc1.bias"]))
+    h = F.linear(h, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+    return x + h, probs
+
+
+def contact_head(sd, tokens, attentions, eos_idx=2, prepend_bos=True, append_eos=True):
+    # reference esm/modules.py:338-357 with symmetrize / apc (modules.py:27-41)
+    if append_eos:
+        keep = tokens.ne(eos_idx).to(attentions)
+        attentions = attentions * (keep[:, :, None] * keep[:, None, :])[:, None, None]
+        attentions = attentions[..., :-1, :-1]
+    if prepend_bos:
+        attentions = attentions[..., 1:, 1:]
+    B, L, H, S, _ = attentions.shape
+    a = attentions.reshape(B, L * H, S, S)
+    a = a + a.transpose(-1, -2)
+    a1 = a.sum(-1, keepdim=True)
+    a2 = a.sum(-2, keepdim=True)
+    a12 = a.sum((-1, -2), keepdim=True)
+    a = a - (a1 * a2) / a12
+    z = F.linear(a.permute(0, 2, 3, 1), sd["contact_head.regression.weight"], sd["contact_head.regression.bias"])
+    return torch.sigmoid(z.squeeze(3))
+
+
+@torch.no_grad()
+def esm2_forward(
+    sd, tokens, num_layers, heads, repr_layers=(), need_head_weights=False, return_contacts=False,
+    token_dropout=True, padding_idx=1, mask_idx=32, eos_idx=2, prepend_bos=True, append_eos=True,
+):
+    """reference esm/model/esm2.py:77-144.  ``sd``: fp32 state dict with the reference's keys."""
+    if return_contacts:
+        need_head_weights = True
+    assert tokens.ndim == 2
+    pad = tokens.eq(padding_idx)  # esm2.py:82
+    x = sd["embed_tokens.weight"][tokens]  # esm2.py:84 (embed_scale = 1)
+    if token_dropout:  # esm2.py:86-92
+        x = x.masked_fill((tokens == mask_idx).unsqueeze(-1), 0.0)
+        mask_ratio_train = 0.15 * 0.8
+        src_lengths = (~pad).sum(-1)
+        ratio = (tokens == mask_idx).sum(-1).to(x.dtype) / src_lengths
+        x = x * (1 - mask_ratio_train) / (1 - ratio)[:, None, None]
+    x = x * (1 - pad.unsqueeze(-1).type_as(x))  # esm2.py:94-95
+    wanted = set(int(i) for i in repr_layers)
+    reps = {}
+    if 0 in wanted:
+        reps[0] = x
+    pad_mask = pad if bool(pad.any()) else None  # esm2.py:108-109
+    attn = []
+    for i in range(num_layers):  # esm2.py:111-121
+        x, probs = transformer_layer(sd, i, x, heads, pad_mask, need_head_weights)
+        if (i + 1) in wanted:
+            reps[i + 1] = x
+        if need_head_weights:
+            attn.append(probs)
+    x = layer_norm(x, sd["emb_layer_norm_after.weight"], sd["emb_layer_norm_after.bias"])  # :123
+    if num_layers in wanted:
+        reps[num_layers] = x  # esm2.py:127-128
+    # RobertaLMHead, reference esm/modules.py:308-314 (weight tied to the embedding, esm2.py:71-75)
+    h = gelu(F.linear(x, sd["lm_head.dense.weight"], sd["lm_head.dense.bias"]))
+    h = layer_norm(h, sd["lm_head.layer_norm.weight"], sd["lm_head.layer_norm.bias"])
+    logits = F.linear(h, sd["embed_tokens.weight"]) + sd["lm_head.bias"]
+    out = {"logits": logits, "representations": reps}
+    if need_head_weights:
+        attentions = torch.stack(attn, 1)  # [B,L,H,T,T], esm2.py:132-139
+        if pad_mask is not None:
+            keep = 1 - pad_mask.type_as(attentions)
+            attentions = attentions * (keep[:, None, :] * keep[:, :, None])[:, None, None]
+        out["attentions"] = attentions
+        if return_contacts:
+            out["contacts"] = contact_head(sd, tokens, attentions, eos_idx, prepend_bos, append_eos)
+    return out

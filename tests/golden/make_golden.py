@@ -1,0 +1,89 @@
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE implementation
+(/root/reference/esm, imported read-only) on seeded synthetic weights.
+
+    python tests/golden/make_golden.py        # only works where /root/reference is mounted
+
+Each fixture stores the token matrix, the model dimensions / synthetic-weight seed (weights are
+regenerated deterministically by esm_amd.synth, a checksum guards against generator drift) and the
+reference outputs in fp32.  The fixtures pin both the oracle (tests/test_oracle.py, CPU) and the
+HIP engine (tests/test_model_gpu.py, MI355X).
+"""
+import importlib
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = "/root/reference"
+
+CASES = {
+    # name: dims, seed, tokens builder
+    "tiny_d64": dict(L=2, E=128, H=2, seed=11, T=20, B=3, keep_attn=True),
+    "mid_d64": dict(L=3, E=256, H=4, seed=12, T=70, B=2, keep_attn=True),
+    "t6_8M_dims": dict(L=6, E=320, H=20, seed=13, T=24, B=2),
+    "nopad_d64": dict(L=2, E=128, H=2, seed=14, T=130, B=2, nopad=True),
+}
+
+
+def build_tokens(B, T, seed, nopad=False):
+    g = torch.Generator().manual_seed(seed)
+    toks = torch.randint(4, 24, (B, T), generator=g, dtype=torch.int64)
+    toks[:, 0] = 0
+    toks[:, -1] = 2
+    if not nopad:
+        # sequence 1 is shorter: eos then pads; a few <mask> tokens; sequence 0 gets a gap and X
+        if B > 1:
+            short = T - max(3, T // 4)
+            toks[1, short] = 2
+            toks[1, short + 1:] = 1
+        toks[0, 3] = 32
+        toks[0, 7] = 32
+        if B > 1:
+            toks[1, 2] = 32
+        toks[0, 5] = 30
+        toks[0, 6] = 24
+        if B > 2:
+            toks[2, T // 2] = 1  # an interior pad (tests/test_load_all.py feeds token 1 mid-row)
+    return toks
+
+
+def main():
+    sys.path.insert(0, ROOT)
+    from esm_amd.synth import synth_esm2_state_dict
+
+    # import the reference package under its own name from /root/reference
+    sys.path.insert(0, REFERENCE)
+    for k in [k for k in sys.modules if k == "esm" or k.startswith("esm.")]:
+        del sys.modules[k]
+    ref = importlib.import_module("esm")
+    assert ref.__file__.startswith(REFERENCE), ref.__file__
+
+    for name, c in CASES.items():
+        sd = synth_esm2_state_dict(c["L"], c["E"], c["H"], seed=c["seed"])
+        model = ref.ESM2(num_layers=c["L"], embed_dim=c["E"], attention_heads=c["H"], alphabet="ESM-1b",
+                         token_dropout=True).eval()
+        model.load_state_dict(sd, strict=True)
+        toks = build_tokens(c["B"], c["T"], c["seed"], c.get("nopad", False))
+        with torch.no_grad():
+            out = model(toks, repr_layers=list(range(c["L"] + 1)), return_contacts=True)
+        fix = {
+            "dims": {k: c[k] for k in ("L", "E", "H", "seed")},
+            "tokens": toks,
+            "weights_checksum": float(sum(v.double().sum() for k, v in sd.items() if k != "lm_head.weight")),
+            "logits": out["logits"].float(),
+            "representations": {k: v.float() for k, v in out["representations"].items()},
+            # full attention maps only for the small cases (file size); contacts pin the rest
+            "attentions": out["attentions"].float() if c.get("keep_attn") else None,
+            "contacts": out["contacts"].float(),
+            "reference_version": getattr(ref, "__version__", "?"),
+            "torch_version": torch.__version__,
+        }
+        path = os.path.join(HERE, f"esm2_{name}.pt")
+        torch.save(fix, path)
+        print(name, "->", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,144 @@
+"""Host-side logic on CPU: tokeniser / batcher golden vectors of the reference's own tests,
+FASTA batching, checkpoint round trip, drop-in names, and the C ABI surface of libesmk.so."""
+import os
+import re
+
+import pytest
+import torch
+
+import esm
+from esm_amd import _native
+from esm_amd.synth import synth_esm2_state_dict, write_esm2_checkpoint
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- reference tests/test_alphabet.py:6-24 ---------------------------------------------------
+def test_alphabet_golden_tokens():
+    alphabet = esm.Alphabet.from_architecture("ESM-1b")
+    conv = alphabet.get_batch_converter()
+    data = [("protein1", "MKTVRQG"), ("protein2 with mask", "KALTA<mask>ISQP"),
+            ("protein3 with mask and spaces", "K A <mask> I S Q")]
+    labels, strs, toks = conv(data)
+    expected = torch.tensor([[0, 20, 15, 11, 7, 10, 16, 6, 2, 1, 1, 1],
+                             [0, 15, 5, 4, 11, 5, 32, 12, 8, 16, 14, 2],
+                             [0, 15, 5, 32, 12, 8, 16, 2, 1, 1, 1, 1]])
+    assert torch.equal(toks, expected)
+    assert labels == [d[0] for d in data] and strs == [d[1] for d in data]
+    assert toks.dtype == torch.int64
+
+
+# ---- reference tests/test_alphabet.py:27-45 --------------------------------------------------
+def test_alphabet_truncation_golden():
+    alphabet = esm.Alphabet.from_architecture("ESM-1b")
+    conv = alphabet.get_batch_converter(truncation_seq_length=10)
+    data = [("p1", "MKTVRQGMKTVRQG"), ("p2", "KALTA<mask>ISQPISQP"), ("p3", "K A <mask> I S Q")]
+    _, strs, toks = conv(data)
+    expected = torch.tensor([[0, 20, 15, 11, 7, 10, 16, 6, 20, 15, 11, 2],
+                             [0, 15, 5, 4, 11, 5, 32, 12, 8, 16, 14, 2],
+                             [0, 15, 5, 32, 12, 8, 16, 2, 1, 1, 1, 1]])
+    assert torch.equal(toks, expected)
+    assert strs[0] == "MKTVRQGMKTVRQG"  # strings stay untruncated
+
+
+# ---- reference tests/test_alphabet.py:64-87 --------------------------------------------------
+def test_msa_batch_converter_golden():
+    alphabet = esm.Alphabet.from_architecture("msa_transformer")
+    conv = alphabet.get_batch_converter()
+    _, _, toks = conv([("1", "MKTVRQG"), ("2", "KALTRAI"), ("3", "KAAISQQ")])
+    expected = torch.tensor([[[0, 20, 15, 11, 7, 10, 16, 6], [0, 15, 5, 4, 11, 10, 5, 12],
+                              [0, 15, 5, 5, 12, 8, 16, 16]]])
+    assert torch.equal(toks, expected)
+    with pytest.raises(RuntimeError):
+        conv([("1", "MKT"), ("2", "MK")])
+
+
+def test_alphabet_ids_and_edge_cases():
+    for arch, n, cls, mask in [("ESM-1b", 33, 0, 32), ("msa_transformer", 33, 0, 32), ("ESM-1", 35, 32, 33)]:
+        a = esm.Alphabet.from_architecture(arch)
+        assert (len(a), a.padding_idx, a.eos_idx, a.unk_idx, a.cls_idx, a.mask_idx) == (n, 1, 2, 3, cls, mask)
+    a = esm.Alphabet.from_architecture("ESM-1b")
+    assert a.all_toks[4:31] == list("LAGVSERTIDPKQNFYMHWCXBUZO.-") and a.all_toks[31] == "<null_1>"
+    assert a.encode("M-K.X") == [20, 30, 15, 29, 24]
+    assert a.encode("<cls>MK<eos>") == [0, 20, 15, 2]
+    assert a.encode("") == [] and a.encode(" ") == []
+    assert a.tokenize("K A <mask> I S Q") == a.tokenize("KA<mask>ISQ")
+    for bad in ("MKJ", "mkt", "*"):
+        with pytest.raises(KeyError):
+            a.encode(bad)
+    with pytest.raises(ValueError):
+        esm.Alphabet.from_architecture("nope")
+    _, strs, toks = a.get_batch_converter(1022)([("a", "A" * 5000)])
+    assert toks.shape == (1, 1024) and toks[0, 0] == 0 and toks[0, -1] == 2 and len(strs[0]) == 5000
+
+
+def test_fasta_dataset_and_batching(tmp_path):
+    lengths = [428, 222, 502, 156, 80, 71, 99, 602, 127, 152, 98, 935, 102, 882, 659]  # some_proteins.fasta
+    fa = tmp_path / "x.fasta"
+    with open(fa, "w") as f:
+        for i, n in enumerate(lengths):
+            f.write(f">seq{i} desc\n")
+            s = "ACDEFGHIKL" * (n // 10 + 1)
+            s = s[:n]
+            for j in range(0, n, 60):
+                f.write(s[j:j + 60] + "\n")
+            f.write("\n")
+    ds = esm.FastaBatchedDataset.from_file(fa)
+    assert len(ds) == 15 and [len(s) for s in ds.sequence_strs] == lengths and ds[0][0] == "seq0 desc"
+    # golden values measured on the reference (SURVEY.md §8 c)
+    assert ds.get_batch_indices(4096, 1) == [[5, 4, 10, 6, 12, 8, 9, 3, 1], [0, 2, 7, 14], [13, 11]]
+    assert ds.get_batch_indices(1024, 1) == [[5, 4, 10, 6, 12, 8], [9, 3, 1], [0, 2], [7], [14], [13], [11]]
+    fb = tmp_path / "y.fasta"
+    fb.write_text(">\nMK\n>a\nTT\n")
+    assert esm.FastaBatchedDataset.from_file(fb).sequence_labels == ["seqnum000000000", "a"]
+    fc = tmp_path / "z.fasta"
+    fc.write_text(">a\nMK\n>a\nTT\n")
+    with pytest.raises(AssertionError):
+        esm.FastaBatchedDataset.from_file(fc)
+    from esm.data import read_fasta
+
+    fd = tmp_path / "w.a3m"
+    fd.write_text(">q\nMK-aT\n>r x\nM.KtT\n")
+    assert list(read_fasta(fd)) == [("q", "MK-aT"), ("r x", "M.KtT")]
+    assert list(read_fasta(fd, keep_gaps=False, keep_insertions=False, to_upper=True)) == [("q", "MKT"), ("r x", "M.KT")]
+
+
+def test_checkpoint_round_trip(tmp_path):
+    path = write_esm2_checkpoint(str(tmp_path), "esm2_t2_tiny_UR50D", 2, 128, 2, seed=5)
+    model, alphabet = esm.pretrained.load_model_and_alphabet(path)
+    assert isinstance(model, esm.ESM2) and len(alphabet) == 33
+    assert (model.num_layers, model.embed_dim, model.attention_heads) == (2, 128, 2)
+    sd = synth_esm2_state_dict(2, 128, 2, seed=5)
+    got = model.state_dict()
+    assert set(got) == set(sd)
+    for k in sd:
+        assert torch.equal(got[k], sd[k]), k
+    assert got["lm_head.weight"].data_ptr() == got["embed_tokens.weight"].data_ptr()  # tied
+    # no regression file -> allowed only for names flagged as such
+    os.remove(str(tmp_path / "esm2_t2_tiny_UR50D-contact-regression.pt"))
+    with pytest.raises(FileNotFoundError):
+        esm.pretrained.load_model_and_alphabet(path)
+    os.rename(path, str(tmp_path / "esm2_t2_tiny_500K_UR50D.pt"))
+    with pytest.warns(UserWarning):
+        esm.pretrained.load_model_and_alphabet(str(tmp_path / "esm2_t2_tiny_500K_UR50D.pt"))
+
+
+def test_state_dict_key_count_8m():
+    m = esm.ESM2(6, 320, 20)
+    assert len(m.state_dict()) == 113  # SURVEY.md §8 b: 113 tensors for the 8M model
+    assert hasattr(esm.pretrained, "esm2_t33_650M_UR50D") and hasattr(esm.pretrained, "esm2_t36_3B_UR50D")
+
+
+def test_forward_refuses_cpu_tensors():
+    m = esm.ESM2(1, 128, 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.tensor([[0, 5, 2]]))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "esmk.h")).read()
+    declared = set(re.findall(r"\b(esmk_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    for name in declared:
+        assert hasattr(_native.lib, name)
+    assert b"gfx950" in _native.lib.esmk_version()
