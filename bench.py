@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: ESM-2 650M bulk embedding extraction on synthetic L=1022 batches.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one forward pass (``model(tokens, repr_layers=[33])``, the call scripts/extract.py:95
+makes) over one batch of B sequences of 1022 residues per GPU, inputs resident in HBM, outputs left
+on the device.  Sequences are independent, so ranks shard the batch with no data-path collective
+(weak scaling); the only collectives are the timing barrier and the MAX over ranks.
+
+Prints ONE JSON line (rank 0): metric residues/sec (whole job), plus
+  roofline     : dominant kernel class vs the fp16/bf16 MFMA roof (2.5 PFLOP/s dense), measured with
+                 HIP events on the launch stream in extra profiled steps after the timed region;
+  cpu_baseline : the oracle (CPU restatement of the reference, oracle/esm2_oracle.py) timed on the
+                 host cores on a bounded sample of the same workload (rank 0, N=1 only), and the
+                 max-abs / relative difference of representations[33] against it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODEL = "esm2_t33_650M_UR50D"
+FLOP_PER_RESIDUE = 1.4769e9  # SURVEY.md §8 d: 1.509 TFLOP per 1024-token sequence / 1022 residues
+MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU per step")
+    ap.add_argument("--seq-len", type=int, default=1022)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2, help="sequences in the CPU baseline sample")
+    args = ap.parse_args()
+
+    import esm
+    from esm_amd.synth import ESM2_DIMS, synth_esm2_state_dict, synth_tokens
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    L, E, H = ESM2_DIMS[MODEL]
+    sd = synth_esm2_state_dict(L, E, H, seed=0)          # identical replica on every rank
+    model = esm.ESM2(L, E, H).eval()
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    toks = synth_tokens(args.batch, args.seq_len, seed=1 + rank).to(dev)  # each rank its own shard
+    residues_per_step = args.batch * args.seq_len
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = model(toks, repr_layers=[L])
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(toks, repr_layers=[L])
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # per-kernel-class timing with HIP events (separate steps so the timed region is unperturbed)
+        prof_steps = 2
+        model.profile_begin()
+        for _ in range(prof_steps):
+            model(toks, repr_layers=[L])
+        prof = model.profile_end()
+
+    value = world * residues_per_step * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    result = None
+    if rank == 0:
+        dom = max(prof, key=lambda e: e["ms"])
+        dom_ms = dom["ms"] / dom["launches"]
+        achieved = dom["flops"] / dom["launches"] / (dom_ms * 1e-3) / 1e12
+        total_ms = sum(e["ms"] for e in prof) / prof_steps
+        classes = {
+            e["name"]: {
+                "ms_per_step": round(e["ms"] / prof_steps, 4),
+                "launches_per_step": e["launches"] // prof_steps,
+                "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 1) if e["flops"] else None,
+                "gbs": round(e["bytes"] / (e["ms"] * 1e-3) / 1e9, 1),
+            }
+            for e in prof
+        }
+        result = {
+            "metric": "residues/sec (whole node) ESM-2 650M L=1022 bulk extract",
+            "value": round(value, 1),
+            "unit": "residues/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{MODEL} forward (repr_layers=[33] + logits), synthetic tokens [B,{args.seq_len + 2}], "
+                            "random-init weights of the 650M architecture",
+                "batch_per_gpu": args.batch, "seq_len": args.seq_len, "sharding": f"dp{world} (no data-path collective)",
+            },
+            "e2e_mfma_frac_per_gpu": round(value / world * FLOP_PER_RESIDUE / (MFMA_PEAK_TFLOPS * 1e12), 4),
+            "roofline": {
+                "kernel": dom["name"],
+                "bound": "mfma",
+                "achieved": round(achieved, 1),
+                "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "avg_launch_ms": round(dom_ms, 4),
+                "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
+            },
+            "kernel_classes": classes,
+            "profiled_ms_per_step": round(total_ms, 3),
+        }
+
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.esm2_oracle import esm2_forward
+
+            # MKL on all 256 hardware threads of the GPU host is 30x SLOWER than on 32 (measured:
+            # 11 vs 354 residues/s, tools/cpu_threads_probe.py); use the best setting found
+            ncores = min(os.cpu_count() or 1, int(os.environ.get("ESM_AMD_CPU_THREADS", "32")))
+            torch.set_num_threads(ncores)
+            sample = toks[: args.cpu_sample].cpu()
+            t_cpu = []
+            ref = None
+            for i in range(3):
+                c0 = time.perf_counter()
+                ref = esm2_forward(sd, sample, L, H, repr_layers=[L])
+                t_cpu.append(time.perf_counter() - c0)
+            t_med = sorted(t_cpu[1:])[0] if len(t_cpu) > 1 else t_cpu[0]
+            cpu_value = sample.shape[0] * args.seq_len / t_med
+            with torch.no_grad():
+                got = model(toks[: args.cpu_sample], repr_layers=[L])
+            r_gpu, r_ref = got["representations"][L].cpu(), ref["representations"][L]
+            max_abs = (r_gpu - r_ref).abs().max().item()
+            rel = max_abs / r_ref.abs().max().item()
+            agree = (got["logits"].cpu().argmax(-1) == ref["logits"].argmax(-1)).float().mean().item()
+            result["cpu_baseline"] = {
+                "value": round(cpu_value, 1),
+                "unit": "residues/s",
+                "cores": torch.get_num_threads(),
+                "kind": "port",
+                "sample": f"{sample.shape[0]} sequences of the timed batch (L={args.seq_len}), fp32 oracle, "
+                          f"best of {len(t_cpu) - 1} after 1 warm-up",
+            }
+            result["parity"] = {
+                "max_abs_repr_diff_vs_cpu": max_abs,
+                "rel_repr_diff_vs_cpu": rel,
+                "logits_argmax_agreement": agree,
+                "sample_sequences": int(sample.shape[0]),
+            }
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

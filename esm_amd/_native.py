@@ -34,6 +34,11 @@ class EsmkConfig(ctypes.Structure):
     ]
 
 
+class EsmkProfileEntry(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 32), ("launches", c_int32), ("ms", ctypes.c_double),
+                ("flops", ctypes.c_double), ("bytes", ctypes.c_double)]
+
+
 # name -> (restype, argtypes); must list every symbol include/esmk.h declares
 SIGNATURES = {
     "esmk_last_error": (c_char_p, []),
@@ -56,6 +61,8 @@ SIGNATURES = {
             c_void_p, c_size_t, c_void_p,
         ],
     ),
+    "esmk_profile_begin": (c_int, [c_void_p]),
+    "esmk_profile_end": (c_int, [c_void_p, POINTER(EsmkProfileEntry), c_int, POINTER(c_int)]),
     "esmk_op_layernorm": (
         c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "esmk_op_linear": (

@@ -55,6 +55,14 @@ struct esmk_model {
     float* d_cos = nullptr;
     float* d_sin = nullptr;
     int rope_cap = 0;
+    // optional per-kernel-class timing with HIP events (esmk_profile_begin / _end)
+    struct ProfRec {
+        int cls;
+        hipEvent_t a, b;
+        double flops, bytes;
+    };
+    bool prof_on = false;
+    std::vector<ProfRec> prof;
 };
 
 namespace {
@@ -156,6 +164,35 @@ int ensure_rope(esmk_model* m, int T, hipStream_t st) {
     m->rope_cap = cap;
     return 0;
 }
+
+enum {
+    PC_EMBED = 0, PC_LAYERNORM, PC_GEMM_QKV, PC_ATTENTION, PC_ATTN_PROBS, PC_GEMM_OUT, PC_GEMM_FC1,
+    PC_GEMM_FC2, PC_COPY, PC_LM_DENSE, PC_LM_LOGITS, PC_CONTACTS, PC_COUNT
+};
+const char* const kProfNames[PC_COUNT] = {
+    "embed", "layernorm", "gemm_qkv_rope", "attention", "attention_probs", "gemm_out_proj",
+    "gemm_fc1_gelu", "gemm_fc2", "repr_copy", "lm_head_dense", "lm_head_logits", "contacts"};
+
+// Brackets one launch with two events on the launch stream when profiling is enabled.
+struct ProfScope {
+    esmk_model* m;
+    hipStream_t st;
+    bool on;
+    ProfScope(esmk_model* m_, hipStream_t st_, int cls, double flops, double bytes)
+        : m(m_), st(st_), on(m_->prof_on) {
+        if (!on) return;
+        esmk_model::ProfRec r{cls, nullptr, nullptr, flops, bytes};
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+            on = false;
+            return;
+        }
+        (void)hipEventRecord(r.a, st);
+        m->prof.push_back(r);
+    }
+    ~ProfScope() {
+        if (on) (void)hipEventRecord(m->prof.back().b, st);
+    }
+};
 
 bool starts_with(const char* s, const char* p) { return strncmp(s, p, strlen(p)) == 0; }
 
@@ -332,10 +369,13 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
 
     if (ensure_rope(m, T, st)) return 1;
 
+    const double NE = (double)N * E;
     auto repr_copy = [&](int layer, const float* src) -> int {
         for (int i = 0; i < n_repr; ++i)
-            if (repr_layers[i] == layer)
+            if (repr_layers[i] == layer) {
+                ProfScope ps(m, st, PC_COPY, 0, 8 * NE);
                 ESMK_TRY(launch_copy_f32(src, (float*)repr_out_dev[i], (size_t)N * E, st));
+            }
         return 0;
     };
     auto wants_repr = [&](int layer) {
@@ -343,12 +383,28 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
             if (repr_layers[i] == layer) return true;
         return false;
     };
+    // algorithmic bytes: operands read once + result written once (residual: read + written)
+    auto gemm = [&](int cls, const GemmArgs& a, int epi, double out_bytes_per_elem) -> int {
+        const double fl = 2.0 * a.M * (double)a.N * a.K;
+        const double by = ((double)a.M * a.K + (double)a.N * a.K) * os + (double)a.M * a.N * out_bytes_per_elem;
+        ProfScope ps(m, st, cls, fl, by);
+        ESMK_TRY(launch_gemm(a, epi, op, st));
+        return 0;
+    };
+    auto lnorm = [&](const float* in, size_t go, size_t bo, void* y, float* y32) -> int {
+        ProfScope ps(m, st, PC_LAYERNORM, 8 * NE, NE * (4 + (y ? os : 0) + (y32 ? 4 : 0)));
+        ESMK_TRY(launch_layernorm(in, (const float*)(pk + go), (const float*)(pk + bo), y, y32, N, E, op, st));
+        return 0;
+    };
 
     // esm2.py:82-95
-    ESMK_TRY(launch_seq_stats(tokens_dev, B, T, m->cfg.pad_idx, m->cfg.mask_idx,
-                              m->cfg.token_dropout, scale, key_bias, seq_info, st));
-    ESMK_TRY(launch_embed(tokens_dev, (const float*)(pk + m->embed_f32), scale, x, B, T, E, m->V,
-                          m->cfg.pad_idx, m->cfg.mask_idx, m->cfg.token_dropout, st));
+    {
+        ProfScope ps(m, st, PC_EMBED, 0, (double)N * 8 + 4 * NE);
+        ESMK_TRY(launch_seq_stats(tokens_dev, B, T, m->cfg.pad_idx, m->cfg.mask_idx,
+                                  m->cfg.token_dropout, scale, key_bias, seq_info, st));
+        ESMK_TRY(launch_embed(tokens_dev, (const float*)(pk + m->embed_f32), scale, x, B, T, E, m->V,
+                              m->cfg.pad_idx, m->cfg.mask_idx, m->cfg.token_dropout, st));
+    }
     if (repr_copy(0, x)) return 1;  // esm2.py:99-100
 
     GemmArgs g;
@@ -357,8 +413,7 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         // keys in [T,Tp) of V^T get probability exactly 0 but must be finite; the region is
         // shared with the FFN intermediate, so it is cleared every layer (odd T only).
         if (w.Tp != T) ESMK_TRY(hipMemsetAsync(vt, 0, (size_t)B * H * 64 * w.Tp * os, st));
-        ESMK_TRY(launch_layernorm(x, (const float*)(pk + o.ln1g), (const float*)(pk + o.ln1b), h,
-                                  nullptr, N, E, op, st));
+        if (lnorm(x, o.ln1g, o.ln1b, h, nullptr)) return 1;
         g = GemmArgs();
         g.A = h;
         g.W = pk + o.wqkv;
@@ -376,11 +431,17 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.E = E;
         g.Tp = w.Tp;
         g.scaling = 1.0f / sqrtf((float)m->D);
-        ESMK_TRY(launch_gemm(g, EPI_QKV_ROPE, op, st));
-        ESMK_TRY(launch_attention(q, k, vt, key_bias, seq_info, h, lse, B, H, T, w.Tp, op, st));
-        if (want_attn)
+        if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;
+        {
+            // 4 T d flop per (query, head) pair: QK^T and PV; q,k,v read + ctx written
+            ProfScope ps(m, st, PC_ATTENTION, 4.0 * N * (double)T * E, 4 * NE * os);
+            ESMK_TRY(launch_attention(q, k, vt, key_bias, seq_info, h, lse, B, H, T, w.Tp, op, st));
+        }
+        if (want_attn) {
+            ProfScope ps(m, st, PC_ATTN_PROBS, 2.0 * N * (double)T * E, 2 * NE * os + 4.0 * N * T * H);
             ESMK_TRY(launch_attention_probs(q, k, lse, key_bias, (float*)attn_out_dev, B, H, T, l, L,
                                             op, st));
+        }
         g = GemmArgs();
         g.A = h;
         g.W = pk + o.wo;
@@ -389,9 +450,8 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.M = N;
         g.N = E;
         g.K = E;
-        ESMK_TRY(launch_gemm(g, EPI_RESID_F32, op, st));
-        ESMK_TRY(launch_layernorm(x, (const float*)(pk + o.ln2g), (const float*)(pk + o.ln2b), h,
-                                  nullptr, N, E, op, st));
+        if (gemm(PC_GEMM_OUT, g, EPI_RESID_F32, 8)) return 1;
+        if (lnorm(x, o.ln2g, o.ln2b, h, nullptr)) return 1;
         g = GemmArgs();
         g.A = h;
         g.W = pk + o.w1;
@@ -400,7 +460,7 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.M = N;
         g.N = F;
         g.K = E;
-        ESMK_TRY(launch_gemm(g, EPI_GELU_T, op, st));
+        if (gemm(PC_GEMM_FC1, g, EPI_GELU_T, os)) return 1;
         g = GemmArgs();
         g.A = ffn;
         g.W = pk + o.w2;
@@ -409,7 +469,7 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.M = N;
         g.N = E;
         g.K = F;
-        ESMK_TRY(launch_gemm(g, EPI_RESID_F32, op, st));
+        if (gemm(PC_GEMM_FC2, g, EPI_RESID_F32, 8)) return 1;
         if (l + 1 < L && repr_copy(l + 1, x)) return 1;  // esm2.py:117-118
     }
 
@@ -421,8 +481,7 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
             break;
         }
     if (want_logits || wants_repr(L)) {
-        ESMK_TRY(launch_layernorm(x, (const float*)(pk + m->fin_g), (const float*)(pk + m->fin_b),
-                                  want_logits ? h : nullptr, rep_last, N, E, op, st));
+        if (lnorm(x, m->fin_g, m->fin_b, want_logits ? h : nullptr, rep_last)) return 1;
         for (int i = 0; i < n_repr; ++i)  // duplicates of layer L, if any
             if (repr_layers[i] == L && repr_out_dev[i] != rep_last)
                 ESMK_TRY(launch_copy_f32(rep_last, (float*)repr_out_dev[i], (size_t)N * E, st));
@@ -436,9 +495,8 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.M = N;
         g.N = E;
         g.K = E;
-        ESMK_TRY(launch_gemm(g, EPI_GELU_F32, op, st));
-        ESMK_TRY(launch_layernorm(g32, (const float*)(pk + m->lm_lng), (const float*)(pk + m->lm_lnb),
-                                  h, nullptr, N, E, op, st));
+        if (gemm(PC_LM_DENSE, g, EPI_GELU_F32, 4)) return 1;
+        if (lnorm(g32, m->lm_lng, m->lm_lnb, h, nullptr)) return 1;
         g = GemmArgs();
         g.A = h;
         g.W = pk + m->embed_op;
@@ -447,13 +505,53 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.M = N;
         g.N = m->V;
         g.K = E;
-        ESMK_TRY(launch_gemm(g, EPI_STORE_F32, op, st));
+        if (gemm(PC_LM_LOGITS, g, EPI_STORE_F32, 4)) return 1;
     }
-    if (want_contacts)  // esm2.py:140-142 -> modules.py:338-357
+    if (want_contacts) {  // esm2.py:140-142 -> modules.py:338-357
+        ProfScope ps(m, st, PC_CONTACTS, 0, 2.0 * 4 * B * (double)L * H * T * T);
         ESMK_TRY(launch_contacts((const float*)attn_out_dev, tokens_dev, (const float*)(pk + m->ct_w),
                                  (const float*)(pk + m->ct_b), (float*)(ws + w.ct_scratch),
                                  (float*)contacts_out_dev, B, L * H, T, m->cfg.eos_idx,
                                  m->cfg.prepend_bos, m->cfg.append_eos, st));
+    }
+    return 0;
+}
+
+int esmk_profile_begin(esmk_model* m) {
+    if (!m) return fail("esmk_profile_begin: null model");
+    for (auto& r : m->prof) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    m->prof.clear();
+    m->prof_on = true;
+    return 0;
+}
+
+int esmk_profile_end(esmk_model* m, esmk_profile_entry* out, int max_entries, int* n_out) {
+    if (!m || !out || !n_out) return fail("esmk_profile_end: null argument");
+    m->prof_on = false;
+    std::vector<esmk_profile_entry> agg(PC_COUNT);
+    for (int c = 0; c < PC_COUNT; ++c) {
+        memset(&agg[c], 0, sizeof(esmk_profile_entry));
+        strncpy(agg[c].name, kProfNames[c], sizeof(agg[c].name) - 1);
+    }
+    for (auto& r : m->prof) {
+        ESMK_TRY(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        ESMK_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        agg[r.cls].launches += 1;
+        agg[r.cls].ms += ms;
+        agg[r.cls].flops += r.flops;
+        agg[r.cls].bytes += r.bytes;
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    m->prof.clear();
+    int n = 0;
+    for (int c = 0; c < PC_COUNT && n < max_entries; ++c)
+        if (agg[c].launches > 0) out[n++] = agg[c];
+    *n_out = n;
     return 0;
 }
 

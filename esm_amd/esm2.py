@@ -262,6 +262,24 @@ class ESM2(nn.Module):
                 result["contacts"] = cast(contacts)
         return result
 
+    def profile_begin(self):
+        """Arm per-kernel-class HIP-event timing of the following forward calls (bench.py)."""
+        from . import _native as N
+
+        if self._engine is None:
+            raise RuntimeError("run one forward before profiling")
+        N.check(N.lib.esmk_profile_begin(self._engine.handle))
+
+    def profile_end(self):
+        """Stop profiling; returns [{name, launches, ms, flops, bytes}] summed over the calls."""
+        from . import _native as N
+
+        buf = (N.EsmkProfileEntry * 32)()
+        n = ctypes.c_int()
+        N.check(N.lib.esmk_profile_end(self._engine.handle, buf, 32, ctypes.byref(n)))
+        return [dict(name=buf[i].name.decode(), launches=buf[i].launches, ms=buf[i].ms, flops=buf[i].flops,
+                     bytes=buf[i].bytes) for i in range(n.value)]
+
     def refresh_engine(self):
         """Drop the engine state (call after replacing Parameter objects or sub-modules)."""
         if self._engine is not None:

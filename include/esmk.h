@@ -95,6 +95,21 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
                  void* contacts_out_dev, void* workspace_dev, size_t workspace_bytes,
                  void* stream);
 
+/* Per-kernel-class timing of esmk_forward with HIP events recorded on the launch stream
+ * (measurement support for bench.py; the reference has no counterpart).
+ * esmk_profile_begin() arms it; every launch of the following esmk_forward() calls is bracketed
+ * by two events; esmk_profile_end() waits for them and returns one aggregated entry per class:
+ * launches, total milliseconds, algorithmic FLOPs and algorithmic bytes. */
+typedef struct esmk_profile_entry {
+    char name[32];
+    int32_t launches;
+    double ms;
+    double flops;
+    double bytes;
+} esmk_profile_entry;
+int esmk_profile_begin(esmk_model* m);
+int esmk_profile_end(esmk_model* m, esmk_profile_entry* out, int max_entries, int* n_out);
+
 /* ---- single-kernel entry points (used by the parity tests and micro-benchmarks) -------- */
 
 /* ESM1bLayerNorm == torch.nn.LayerNorm(E, eps=1e-5) (esm/modules.py:68-81).
