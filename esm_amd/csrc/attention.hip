@@ -197,21 +197,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     // ---- normalise and store ctx[b*T + q][head*64 + dv] ---------------------------------------
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / ltot;
-    const int qrow = q0 + lm;
-    if (qrow < Tlen) {
-        T* dst = ctx + ((size_t)b * Tlen + qrow) * ((size_t)H * 64) + head * 64;
+    // Stage the wave's [32 queries][64 dv] block through its private 4 KiB LDS slice (all waves
+    // have passed the last barrier, the K/V buffers are dead) so that the global stores are 16 B
+    // per lane and cover whole 128-byte rows instead of 8-byte pieces of 32 different rows.
+    using V4 = typename Op<T>::v4;
+    char* wl = smem + wave * 4096;
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+    for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                typename Op<T>::v4 pk;
+        for (int g = 0; g < 4; ++g) {
+            V4 pk;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = Op<T>::from(o[d][4 * g + e] * inv);
-                *reinterpret_cast<typename Op<T>::v4*>(dst + d * 32 + 8 * g + 4 * h) = pk;
-            }
-        if (lse != nullptr && h == 0)
-            lse[(size_t)bh * Tlen + qrow] = m2 * (1.0f / LOG2E) + logf(ltot);
+            for (int e = 0; e < 4; ++e) pk[e] = Op<T>::from(o[d][4 * g + e] * inv);
+            *reinterpret_cast<V4*>(wl + lm * 128 + (((4 * d + g) ^ (lm & 7)) << 4) + 8 * h) = pk;
+        }
+    T* dst = ctx + ((size_t)b * Tlen) * ((size_t)H * 64) + head * 64;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int pc = it * 64 + lane;
+        const int r = pc >> 3, c = pc & 7;
+        const V8 v = *reinterpret_cast<const V8*>(wl + r * 128 + ((c ^ (r & 7)) << 4));
+        if (q0 + r < Tlen) *reinterpret_cast<V8*>(dst + (size_t)(q0 + r) * ((size_t)H * 64) + c * 8) = v;
     }
+    const int qrow = q0 + lm;
+    if (lse != nullptr && h == 0 && qrow < Tlen)
+        lse[(size_t)bh * Tlen + qrow] = m2 * (1.0f / LOG2E) + logf(ltot);
 }
 
 hipError_t launch_attention(const void* q, const void* k, const void* vt, const float* key_bias,

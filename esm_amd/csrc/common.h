@@ -57,6 +57,20 @@ ESMK_DEV void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // exact-erf GELU, reference esm/modules.py:17-24:  x * 0.5 * (1 + erf(x / sqrt(2)))
 ESMK_DEV float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// Same function through erfc(|z|) ~= poly(t) exp(-z^2), t = 1/(1 + p|z|) (Abramowitz-Stegun 7.1.26,
+// |error| <= 1.5e-7): |gelu_fast - gelu_erf| <= 3.4e-7 over the whole real line (checked against
+// float64 on 2e6 points), i.e. ~1000x below the fp16 rounding of the value it feeds; 1 rcp + 1 exp2
+// + 9 FMA/MUL instead of the branchy libm erff.
+ESMK_DEV float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly =
+        t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float q = poly * __builtin_amdgcn_exp2f(-(z * z) * 1.4426950408889634f);  // erfc(|z|)
+    const float hq = 0.5f * x * q;
+    return x >= 0.f ? x - hq : hq;
+}
+
 ESMK_DEV float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

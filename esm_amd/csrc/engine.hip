@@ -419,7 +419,7 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.W = pk + o.wqkv;
         g.bias = (const float*)(pk + o.bqkv);
         g.M = N;
-        g.N = 3 * E;
+        g.N = 2 * E;
         g.K = E;
         g.q = q;
         g.k = k;
@@ -431,7 +431,11 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.E = E;
         g.Tp = w.Tp;
         g.scaling = 1.0f / sqrtf((float)m->D);
-        if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;
+        if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;  // q, k: weight rows [0,2E)
+        g.W = pk + o.wqkv + (size_t)2 * E * E * os;             // v: weight rows [2E,3E)
+        g.bias = (const float*)(pk + o.bqkv) + 2 * E;
+        g.N = E;
+        if (gemm(PC_GEMM_QKV, g, EPI_V_T, os)) return 1;
         {
             // 4 T d flop per (query, head) pair: QK^T and PV; q,k,v read + ctx written
             ProfScope ps(m, st, PC_ATTENTION, 4.0 * N * (double)T * E, 4 * NE * os);
@@ -577,10 +581,9 @@ int esmk_op_linear(const void* a_dev, const void* w_dev, const float* bias_dev, 
     g.M = M;
     g.N = N;
     g.K = K;
-    if (operand_dtype & 0x100) {  // test hook: force the generic 64x64 kernel
-        g.force_generic = 1;
-        operand_dtype &= 0xff;
-    }
+    if (operand_dtype & 0x100) g.force_generic = 1;  // test hook: force the generic 64x64 kernel
+    g.dbg = (operand_dtype >> 12) & 0xff;             // timing experiments (tools/microbench.py)
+    operand_dtype &= 0xff;
     ESMK_TRY(launch_gemm(g, epilogue, operand_dtype, (hipStream_t)stream));
     return 0;
 }
@@ -600,7 +603,7 @@ int esmk_op_qkv_rope(esmk_model* m, const void* a_dev, const void* wqkv_dev,
     g.W = wqkv_dev;
     g.bias = bias_dev;
     g.M = B * T;
-    g.N = 3 * m->E;
+    g.N = 2 * m->E;
     g.K = m->E;
     g.q = q_out;
     g.k = k_out;
@@ -613,6 +616,10 @@ int esmk_op_qkv_rope(esmk_model* m, const void* a_dev, const void* wqkv_dev,
     g.Tp = Tp;
     g.scaling = 1.0f / sqrtf((float)m->D);
     ESMK_TRY(launch_gemm(g, EPI_QKV_ROPE, m->cfg.operand_dtype, st));
+    g.W = (const char*)wqkv_dev + (size_t)2 * m->E * m->E * op_size(m->cfg.operand_dtype);
+    g.bias = bias_dev + 2 * m->E;
+    g.N = m->E;
+    ESMK_TRY(launch_gemm(g, EPI_V_T, m->cfg.operand_dtype, st));
     return 0;
 }
 

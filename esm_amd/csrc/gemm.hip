@@ -5,7 +5,7 @@
 // what the reference runs as separate elementwise ops into the epilogue:
 //   * bias add,
 //   * q scaling (multihead_attention.py:261), rotary embedding (rotary_embedding.py:11-20,63-69)
-//     and the head split / transpose (multihead_attention.py:280-284)        -> EPI_QKV_ROPE
+//     and the head split / transpose (multihead_attention.py:280-284)        -> EPI_QKV_ROPE (q,k), EPI_V_T (v)
 //   * exact-erf GELU (modules.py:17-24)                                      -> EPI_GELU_*
 //   * residual add into the fp32 stream (modules.py:134,140)                 -> EPI_RESID_F32
 //
@@ -35,110 +35,225 @@ namespace esmk {
 // --------------------------------------------------------------------------------------------
 // epilogue
 // --------------------------------------------------------------------------------------------
+// Every wave owns a [128 (m)] x [64 (n)] block of the output tile and, once the K loop is done,
+// a private 16 KiB slice of the (now idle) LDS.  The MFMA accumulator layout gives a lane 4
+// consecutive columns of 32 different rows, i.e. 8-byte pieces scattered over 32 cache lines per
+// store instruction; instead the block is first written to the LDS slice (XOR-swizzled 16-byte
+// chunks) and then drained row by row with 16 B per lane, so every global store instruction
+// covers whole 128 B / 256 B row segments (8 or 4 full rows per instruction).
 template <typename T>
-ESMK_DEV void store4(T* dst, float a, float b, float c, float d) {
+ESMK_DEV typename Op<T>::v4 pack4(float a, float b, float c, float d) {
     typename Op<T>::v4 v;
     v[0] = Op<T>::from(a);
     v[1] = Op<T>::from(b);
     v[2] = Op<T>::from(c);
     v[3] = Op<T>::from(d);
-    *reinterpret_cast<typename Op<T>::v4*>(dst) = v;
+    return v;
 }
 
-// One wave owns a [128 (m)] x [64 (n)] block: acc[j][i][r], j = 32-col tile, i = 32-row tile.
-// lane: m = m_base + 32 i + (lane & 31);  n = n_base + 32 j + 8 (r>>2) + 4 (lane>>5) + (r&3).
+// layout A: [128 rows][128 B]  (64 operand-dtype elements per row), chunk c in [0,8)
+ESMK_DEV int lds_a(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+// layout B: [64 rows][256 B]   (64 fp32 or 128 operand-dtype elements per row), chunk c in [0,16)
+ESMK_DEV int lds_b(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
+
+// acc[j][i][r] in the "swapped" orientation (MFMA A operand = weight rows):
+//   m = m_base + 32 i + (lane & 31);  n = n_base + 32 j + 8 (r>>2) + 4 (lane>>5) + (r&3).
+// With vswap (V tiles of the fused QKV projection, MFMA A operand = activation rows):
+//   n = n_base + 32 j + (lane & 31);  m = m_base + 32 i + 8 (r>>2) + 4 (lane>>5) + (r&3).
 template <typename T, int EPI>
 ESMK_DEV void epilogue_wave(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int n_base,
-                            int lane) {
+                            int lane, char* wl) {
+    using V4 = typename Op<T>::v4;
+    using V8 = typename Op<T>::v8;
     const int h = lane >> 5, lm = lane & 31;
-    if constexpr (EPI == EPI_QKV_ROPE) {
-        // the wave's 64 columns are exactly one head of q, k or v (needs head_dim == 64)
-        if (n_base >= p.N) return;
-        const int which = n_base / p.E;            // 0 q, 1 k, 2 v   (wave uniform)
-        const int head = (n_base - which * p.E) >> 6;
-        T* q_or_k = reinterpret_cast<T*>(which == 0 ? p.q : p.k);
+    if (n_base >= p.N || m_base >= p.M) return;
+    if constexpr (EPI == EPI_V_T) {
+        // V projection, accumulated with exchanged MFMA operands: the lane owns output channel
+        // dv = 32 j + (lane & 31) and 4 consecutive tokens.  Result goes to vt[b][head][dv][Tp]
+        // with keys permuted inside groups of 16 (4-groups 1 and 2 swapped) so the attention kernel
+        // reads the 8 keys of one MFMA k-slot as 16 contiguous bytes.
+        const int head = n_base >> 6;
+        const bool aligned = (p.T % 128 == 0);  // the wave's 128 tokens = one aligned run of one sequence
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int dv = 32 * j + lm;
+            const float bv = p.bias[n_base + dv];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    // aligned: store in the permuted key order; otherwise in token order
+                    const int chunk = aligned ? 4 * i + 2 * (g >> 1) + h : 4 * i + g;
+                    const int half = aligned ? (g & 1) : h;
+                    *reinterpret_cast<V4*>(wl + lds_b(dv, chunk) + 8 * half) =
+                        pack4<T>(acc[j][i][4 * g] + bv, acc[j][i][4 * g + 1] + bv,
+                                 acc[j][i][4 * g + 2] + bv, acc[j][i][4 * g + 3] + bv);
+                }
+        }
         T* vt = reinterpret_cast<T*>(p.vt);
+        if (aligned) {
+            const int b = m_base / p.T, t0 = m_base - b * p.T;
+            T* base = vt + ((size_t)(b * p.H + head) * 64) * p.Tp + t0;
+            V8 v[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int pc = it * 64 + lane;
+                v[it] = *reinterpret_cast<const V8*>(wl + lds_b(pc >> 4, pc & 15));
+            }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int pc = it * 64 + lane;
+                *reinterpret_cast<V8*>(base + (size_t)(pc >> 4) * p.Tp + (pc & 15) * 8) = v[it];
+            }
+        } else {
+            // any T: per-element stores with the key permutation applied per token
+#pragma unroll 1
+            for (int idx = lane; idx < 64 * 128; idx += 64) {
+                const int r = idx >> 7, tl = idx & 127;
+                const int m = m_base + tl;
+                if (m >= p.M) continue;
+                const T v = *reinterpret_cast<const T*>(wl + lds_b(r, tl >> 3) + 2 * (tl & 7));
+                const int b = m / p.T, t = m - b * p.T;
+                const int t16 = t & 15;
+                const int tp = (t & ~15) | ((((t16 >> 2) & 1) << 3) | (((t16 >> 3) & 1) << 2) | (t16 & 3));
+                vt[((size_t)(b * p.H + head) * 64 + r) * (size_t)p.Tp + tp] = v;
+            }
+        }
+    } else if constexpr (EPI == EPI_QKV_ROPE) {
+        // q and k projections (N = 2E): the wave's 64 columns are exactly one head (head_dim 64)
+        const int which = n_base / p.E;  // 0 q, 1 k   (wave uniform)
+        const int head = (n_base - which * p.E) >> 6;
+        // q / k: bias, q scaling (mha.py:261), rotation (rotary_embedding.py:11-20) -> LDS rows
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = m_base + 32 * i + lm;
-            if (m >= p.M) continue;
-            const int b = m / p.T, t = m - b * p.T;
-            const size_t bh = (size_t)b * p.H + head;
+            const int row = 32 * i + lm;
+            const int m = min(m_base + row, p.M - 1);
+            const int t = m % p.T;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = 8 * g + 4 * h;  // first of 4 consecutive dims in [0,32)
                 const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n_base + d0);
                 const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.bias + n_base + 32 + d0);
-                float x1[4], x2[4];
+                const f32x4 c = *reinterpret_cast<const f32x4*>(p.cos + (size_t)t * 32 + d0);
+                const f32x4 s = *reinterpret_cast<const f32x4*>(p.sin + (size_t)t * 32 + d0);
+                float y1[4], y2[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    x1[e] = acc[0][i][4 * g + e] + b1[e];
-                    x2[e] = acc[1][i][4 * g + e] + b2[e];
-                }
-                if (which == 2) {
-                    // V transposed: vt[b][head][dv][Tp], key index permuted inside groups of 16
-                    // (4-groups 1 and 2 swapped) so the attention kernel reads 8 keys as 16 B.
-                    const int t16 = t & 15;
-                    const int tp = (t & ~15) | ((((t16 >> 2) & 1) << 3) | (((t16 >> 3) & 1) << 2) |
-                                                (t16 & 3));
-                    T* base = vt + (bh * 64) * (size_t)p.Tp + tp;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        base[(size_t)(d0 + e) * p.Tp] = Op<T>::from(x1[e]);
-                        base[(size_t)(32 + d0 + e) * p.Tp] = Op<T>::from(x2[e]);
+                    float a1 = acc[0][i][4 * g + e] + b1[e];
+                    float a2 = acc[1][i][4 * g + e] + b2[e];
+                    if (which == 0) {
+                        a1 *= p.scaling;
+                        a2 *= p.scaling;
                     }
-                } else {
-                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.cos + (size_t)t * 32 + d0);
-                    const f32x4 s = *reinterpret_cast<const f32x4*>(p.sin + (size_t)t * 32 + d0);
-                    float y1[4], y2[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float a1 = x1[e], a2 = x2[e];
-                        if (which == 0) {  // q *= head_dim^-0.5 before the rotation (mha.py:261)
-                            a1 *= p.scaling;
-                            a2 *= p.scaling;
-                        }
-                        // x*cos + rotate_half(x)*sin, rotate_half(x) = cat(-x2, x1)
-                        y1[e] = a1 * c[e] - a2 * s[e];
-                        y2[e] = a2 * c[e] + a1 * s[e];
-                    }
-                    T* dst = q_or_k + (bh * p.T + t) * 64;
-                    store4<T>(dst + d0, y1[0], y1[1], y1[2], y1[3]);
-                    store4<T>(dst + 32 + d0, y2[0], y2[1], y2[2], y2[3]);
+                    // x*cos + rotate_half(x)*sin, rotate_half(x) = cat(-x2, x1)
+                    y1[e] = a1 * c[e] - a2 * s[e];
+                    y2[e] = a2 * c[e] + a1 * s[e];
                 }
+                *reinterpret_cast<V4*>(wl + lds_a(row, g) + 8 * h) = pack4<T>(y1[0], y1[1], y1[2], y1[3]);
+                *reinterpret_cast<V4*>(wl + lds_a(row, 4 + g) + 8 * h) = pack4<T>(y2[0], y2[1], y2[2], y2[3]);
             }
         }
-    } else {
+        T* qk = reinterpret_cast<T*>(which == 0 ? p.q : p.k);
+        V8 v[16];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int it = 0; it < 16; ++it) {
+            const int pc = it * 64 + lane;
+            v[it] = *reinterpret_cast<const V8*>(wl + lds_a(pc >> 3, pc & 7));
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int pc = it * 64 + lane;
+            const int m = m_base + (pc >> 3);
+            if (m < p.M) {
+                const int b = m / p.T, t = m - b * p.T;
+                *reinterpret_cast<V8*>(qk + ((size_t)(b * p.H + head) * p.T + t) * 64 + (pc & 7) * 8) = v[it];
+            }
+        }
+    } else if constexpr (EPI == EPI_STORE_T || EPI == EPI_GELU_T) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = n_base + 32 * j + 8 * g + 4 * h;
-                if (n >= p.N) continue;
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+                if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int m = m_base + 32 * i + lm;
-                    if (m >= p.M) continue;
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[e] = acc[j][i][4 * g + e] + bv[e];
-                        if constexpr (EPI == EPI_GELU_T || EPI == EPI_GELU_F32) v[e] = gelu_erf(v[e]);
+                        if constexpr (EPI == EPI_GELU_T) v[e] = gelu_fast(v[e]);
                     }
-                    const size_t o = (size_t)m * p.N + n;
-                    if constexpr (EPI == EPI_STORE_T || EPI == EPI_GELU_T) {
-                        store4<T>(reinterpret_cast<T*>(p.out) + o, v[0], v[1], v[2], v[3]);
-                    } else if constexpr (EPI == EPI_RESID_F32) {
-                        f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o);
-                        f32x4 old = *dst;
-                        f32x4 nv = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
-                        *dst = nv;
-                    } else {
-                        f32x4 nv = {v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = nv;
+                    *reinterpret_cast<V4*>(wl + lds_a(32 * i + lm, 4 * j + g) + 8 * h) =
+                        pack4<T>(v[0], v[1], v[2], v[3]);
+                }
+            }
+        T* out = reinterpret_cast<T*>(p.out);
+        V8 v[16];  // all LDS reads first, then the stores (no per-row LDS round trip)
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int pc = it * 64 + lane;
+            v[it] = *reinterpret_cast<const V8*>(wl + lds_a(pc >> 3, pc & 7));
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int pc = it * 64 + lane;
+            const int m = m_base + (pc >> 3), n = n_base + (pc & 7) * 8;
+            if (m < p.M && n < p.N) *reinterpret_cast<V8*>(out + (size_t)m * p.N + n) = v[it];
+        }
+    } else {
+        // fp32 outputs: two passes of 64 rows x 256 B
+        float* out = reinterpret_cast<float*>(p.out);
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n_base + 32 * j + 8 * g + 4 * h;
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const int i = 2 * hp + ii;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[j][i][4 * g + e] + bv[e];
+                            if constexpr (EPI == EPI_GELU_F32) v[e] = gelu_fast(v[e]);
+                        }
+                        *reinterpret_cast<f32x4*>(wl + lds_b(32 * ii + lm, 8 * j + 2 * g + h)) = v;
                     }
+                }
+            // 2 x 8 row groups: all LDS reads and all residual loads are issued before the first
+            // dependent add / store (tail rows and columns are clamped for the load, predicated
+            // for the store)
+#pragma unroll
+            for (int q8 = 0; q8 < 2; ++q8) {
+                f32x4 v[8], old[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int pc = (8 * q8 + u) * 64 + lane;
+                    v[u] = *reinterpret_cast<const f32x4*>(wl + lds_b(pc >> 4, pc & 15));
+                }
+                if constexpr (EPI == EPI_RESID_F32) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int pc = (8 * q8 + u) * 64 + lane;
+                        const int m = min(m_base + 64 * hp + (pc >> 4), p.M - 1);
+                        const int n = min(n_base + (pc & 15) * 4, p.N - 4);
+                        old[u] = *reinterpret_cast<const f32x4*>(out + (size_t)m * p.N + n);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int pc = (8 * q8 + u) * 64 + lane;
+                    const int m = m_base + 64 * hp + (pc >> 4), n = n_base + (pc & 15) * 4;
+                    f32x4 r = v[u];
+                    if constexpr (EPI == EPI_RESID_F32)
+                        r = f32x4{old[u][0] + r[0], old[u][1] + r[1], old[u][2] + r[2], old[u][3] + r[3]};
+                    if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = r;
                 }
             }
         }
@@ -153,7 +268,9 @@ constexpr int G_TILE_BYTES = G_BM * G_BK * 2;  // 32 KiB per operand per stage
 constexpr int G_STAGE_BYTES = 2 * G_TILE_BYTES;
 constexpr int G_LDS_BYTES = 2 * G_STAGE_BYTES;  // 128 KiB
 
-template <typename T, int EPI>
+// DBG != 0 builds timing-experiment variants (tools/microbench.py --only dbg), results are wrong:
+// bit 0 no staging in the loop, bit 1 no vmcnt wait / barrier, bit 2 MFMA only (no LDS reads).
+template <typename T, int EPI, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -177,20 +294,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     for (int j = 0; j < 4; ++j) {
         const int pos = j * 512 + tid;
         const int r = pos >> 3, s = pos & 7;
-        const int c = s ^ ((r >> 1) & 7);
+        const int c = (DBG & 16) ? s : (s ^ ((r >> 1) & 7));
         const int ra = min(m0 + r, p.M - 1);
         const int rw = min(n0 + r, p.N - 1);
         ga[j] = A + (size_t)ra * p.K + c * 8;
         gw[j] = W + (size_t)rw * p.K + c * 8;
     }
 
-    auto stage = [&](int buf, int kt) {
+    // One staging "part" = round j of the activation tile + round j of the weight tile (2 LDS-DMA
+    // instructions per wave, 16 KiB per workgroup); a K tile is 4 parts.
+    auto stage_part = [&](int buf, int kt, int j) {
         char* base = smem + buf * G_STAGE_BYTES;
+        const int ko = (DBG & 32) ? 0 : kt * G_BK;  // DBG 32: re-read K slab 0 (all L2 hits)
+        glds16(ga[j] + ko, base + (j * 512 + wave * 64) * 16);
+        glds16(gw[j] + ko, base + G_TILE_BYTES + (j * 512 + wave * 64) * 16);
+    };
+    auto stage = [&](int buf, int kt) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds16(ga[j] + kt * G_BK, base + (j * 512 + wave * 64) * 16);
-            glds16(gw[j] + kt * G_BK, base + G_TILE_BYTES + (j * 512 + wave * 64) * 16);
-        }
+        for (int j = 0; j < 4; ++j) stage_part(buf, kt, j);
     };
 
     // fragment read offsets (bytes) inside a tile
@@ -210,35 +331,109 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
+    using V8 = typename Op<T>::v8;
+    struct Frags {
+        V8 w[2], a[4];
+    };
+    auto read_frags = [&](Frags& f, const char* sb, int ks) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) f.w[j] = *reinterpret_cast<const V8*>(sb + w_off + j * 4096 + xo[ks]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f.a[i] = *reinterpret_cast<const V8*>(sb + a_off + i * 4096 + xo[ks]);
+    };
+    auto mma8 = [&](const Frags& f) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (EPI == EPI_V_T)  // lane owns 4 consecutive tokens of one channel
+                    acc[j][i] = Op<T>::mma(f.a[i], f.w[j], acc[j][i]);
+                else  // lane owns 4 consecutive channels of one token
+                    acc[j][i] = Op<T>::mma(f.w[j], f.a[i], acc[j][i]);
+            }
+    };
+
+    // Software pipeline: the fragments of k-slice s+1 are requested from the LDS BEFORE the 8 MFMAs
+    // of slice s are issued (two register sets), and the first slice of the NEXT tile is requested
+    // right after the tile barrier, in front of the last 8 MFMAs of the current tile, so LDS
+    // latency and the barrier skew hide behind matrix work instead of idling the pipe.
     const int nk = p.K / G_BK;
+    Frags f0, f1;
     stage(0, 0);
     wait_vmcnt0();
     __syncthreads();
+    read_frags(f0, smem, 0);
 
-    using V8 = typename Op<T>::v8;
+    // `arrived(f)` is an empty asm that "uses" the fragment registers: hipcc places the LDS wait
+    // (lgkmcnt) in front of it, i.e. BEFORE the next slice's reads are issued, when only the needed
+    // reads are outstanding (it otherwise waits for the just-issued prefetch as well).
+    auto arrived = [&](Frags& f) {
+        asm volatile("" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]));
+        __builtin_amdgcn_sched_barrier(0);
+    };
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const bool more = (kt + 1 < nk) && !(DBG & 1);
+        // The LDS-DMA instructions of the next tile are spread over the MFMA groups (SCHED digits =
+        // parts issued in front of group 0..3): a burst of all 64 per CU at the top of the K step
+        // parks every wave in the memory-issue queue while the matrix pipe idles.
+        constexpr int SCHED = (DBG & 64) ? 0x4000 : ((DBG & 128) ? 0x2200 : 0x2110);
+        auto stage_some = [&](int first, int count) {
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j >= first && j < first + count) stage_part(cur ^ 1, kt + 1, j);
+            }
+        };
+        constexpr int C0 = (SCHED >> 12) & 15, C1 = (SCHED >> 8) & 15, C2 = (SCHED >> 4) & 15, C3 = SCHED & 15;
+        static_assert(C0 + C1 + C2 + C3 == 4, "every part exactly once");
         const char* sb = smem + cur * G_STAGE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            V8 wf[2], af[4];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                wf[j] = *reinterpret_cast<const V8*>(sb + w_off + j * 4096 + xo[ks]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                af[i] = *reinterpret_cast<const V8*>(sb + a_off + i * 4096 + xo[ks]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[j][i] = Op<T>::mma(wf[j], af[i], acc[j][i]);
+        if constexpr (DBG & 8) {  // timing experiment: staging only
+            stage_some(0, 4);
+            wait_vmcnt0();
+            __syncthreads();
+            continue;
         }
-        wait_vmcnt0();
-        __syncthreads();
+        if constexpr (DBG & 4) {  // timing experiment: MFMA only
+            mma8(f0);
+            mma8(f0);
+            mma8(f0);
+            mma8(f0);
+            if constexpr (!(DBG & 2)) __syncthreads();
+            continue;
+        }
+        arrived(f0);
+        read_frags(f1, sb, 1);
+        stage_some(0, C0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma8(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        arrived(f1);
+        read_frags(f0, sb, 2);
+        stage_some(C0, C1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma8(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        arrived(f0);
+        read_frags(f1, sb, 3);
+        stage_some(C0 + C1, C2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma8(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        arrived(f1);
+        stage_some(C0 + C1 + C2, C3);
+        if constexpr (!(DBG & 2)) {
+            wait_vmcnt0();     // next tile has landed (issued one whole K step ago)
+            __syncthreads();   // ... for every wave, and every wave is done reading this buffer
+        }
+        read_frags(f0, smem + (cur ^ 1) * G_STAGE_BYTES, 0);  // (harmless stale read after the last tile)
+        __builtin_amdgcn_sched_barrier(0);
+        mma8(f1);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    __syncthreads();  // all MFMA operands consumed before the LDS is reused by the epilogue
 
-    epilogue_wave<T, EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+    epilogue_wave<T, EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * 16384);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -306,10 +501,10 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs p) {
 // --------------------------------------------------------------------------------------------
 // host launchers
 // --------------------------------------------------------------------------------------------
-template <typename T, int EPI>
+template <typename T, int EPI, int DBG = 0>
 static hipError_t launch_fast(const GemmArgs& p, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = gemm256_kernel<T, EPI>;
+    auto kern = gemm256_kernel<T, EPI, DBG>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES);
@@ -330,12 +525,30 @@ static hipError_t launch_generic(const GemmArgs& p, hipStream_t st) {
 
 template <typename T>
 static hipError_t dispatch(const GemmArgs& p, int epi, hipStream_t st) {
-    const bool fast = (p.K % G_BK == 0) && (p.N % 4 == 0) && !p.force_generic;
-    if (epi == EPI_QKV_ROPE) {
-        if (!fast) return hipErrorInvalidValue;
-        return launch_fast<T, EPI_QKV_ROPE>(p, st);
+    const bool fast = (p.K % G_BK == 0) && (p.N % 8 == 0) && !p.force_generic;
+    if (epi == EPI_QKV_ROPE || epi == EPI_V_T) {
+        if (!fast || p.N % 64 != 0) return hipErrorInvalidValue;
+        return epi == EPI_V_T ? launch_fast<T, EPI_V_T>(p, st) : launch_fast<T, EPI_QKV_ROPE>(p, st);
     }
     if (!fast && (p.K % 32 != 0)) return hipErrorInvalidValue;
+    if (p.dbg && fast && epi == EPI_STORE_T) {  // timing experiments
+        switch (p.dbg) {
+            case 1: return launch_fast<T, EPI_STORE_T, 1>(p, st);
+            case 2: return launch_fast<T, EPI_STORE_T, 2>(p, st);
+            case 3: return launch_fast<T, EPI_STORE_T, 3>(p, st);
+            case 5: return launch_fast<T, EPI_STORE_T, 5>(p, st);
+            case 7: return launch_fast<T, EPI_STORE_T, 7>(p, st);
+            case 8: return launch_fast<T, EPI_STORE_T, 8>(p, st);
+            case 16: return launch_fast<T, EPI_STORE_T, 16>(p, st);
+            case 24: return launch_fast<T, EPI_STORE_T, 24>(p, st);
+            case 40: return launch_fast<T, EPI_STORE_T, 40>(p, st);
+            case 32: return launch_fast<T, EPI_STORE_T, 32>(p, st);
+            case 64: return launch_fast<T, EPI_STORE_T, 64>(p, st);
+            case 128: return launch_fast<T, EPI_STORE_T, 128>(p, st);
+            case 96: return launch_fast<T, EPI_STORE_T, 96>(p, st);
+            case 160: return launch_fast<T, EPI_STORE_T, 160>(p, st);
+        }
+    }
 #define ESMK_CASE(E)                                               \
     case E:                                                        \
         return fast ? launch_fast<T, E>(p, st) : launch_generic<T, E>(p, st);

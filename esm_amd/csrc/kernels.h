@@ -13,7 +13,8 @@ enum {
     EPI_GELU_T = 2,     // out operand dtype      = gelu(acc + bias)
     EPI_GELU_F32 = 3,   // out fp32               = gelu(acc + bias)
     EPI_RESID_F32 = 4,  // out fp32              += acc + bias
-    EPI_QKV_ROPE = 5    // fused q/k/v projection epilogue (head_dim 64 only)
+    EPI_QKV_ROPE = 5,   // fused q,k projection: bias, q scale, RoPE, head-major store (head_dim 64)
+    EPI_V_T = 6         // v projection stored transposed [B,H,64,Tp] for the attention kernel
 };
 
 struct GemmArgs {
@@ -23,6 +24,7 @@ struct GemmArgs {
     void* out = nullptr;
     int M = 0, N = 0, K = 0;
     int force_generic = 0;
+    int dbg = 0;  // timing experiments only (tools/microbench.py): 1 no staging, 2 no barrier, 4 no LDS reads
     // EPI_QKV_ROPE only
     void* q = nullptr;   // [B,H,T,64]
     void* k = nullptr;   // [B,H,T,64]

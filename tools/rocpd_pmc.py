@@ -1,0 +1,23 @@
+"""Per-kernel averages of rocprofv3 --pmc counters from rocpd sqlite outputs.
+    python tools/rocpd_pmc.py gpurun_out/pmc_*/*/*_results.db"""
+import re, sqlite3, sys
+from collections import defaultdict
+
+def short(n):
+    m = re.search(r"(gemm256_kernel|gemm64_kernel|attn_fwd_kernel|attn_probs_kernel|layernorm_kernel)I([A-Za-z0-9_]*?)E", n)
+    if m:
+        return m.group(1) + "<" + m.group(2).replace("DF16_", "f16,").replace("DF16b", "bf16,").replace("Li", "") + ">"
+    return re.sub(r"\(.*", "", n)[:60]
+
+acc = defaultdict(lambda: defaultdict(list))
+for path in sys.argv[1:]:
+    c = sqlite3.connect(path)
+    for name, grid, ctr, val, dur in c.execute(
+            "select kernel_name, grid_size, counter_name, value, duration from counters_collection"):
+        acc[(short(name), grid)][ctr].append(val)
+        acc[(short(name), grid)]["_dur_us"].append(dur / 1e3)
+for key in sorted(acc, key=lambda k: -sum(acc[k]["_dur_us"])):
+    if "convert" in key[0] or "copy" in key[0].lower() or "elementwise" in key[0]:
+        continue
+    d = acc[key]
+    print(key[0], "grid", key[1], " ".join(f"{k}={sum(v)/len(v):.4g}" for k, v in sorted(d.items())))
