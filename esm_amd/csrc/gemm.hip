@@ -29,6 +29,8 @@
 // (K % 64 != 0, N % 4 != 0 such as the 33-wide vocabulary projection).
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace esmk {
 
@@ -565,6 +567,12 @@ static hipError_t dispatch(const GemmArgs& p, int epi, hipStream_t st) {
 
 hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipErrorInvalidValue;
+    static const bool env_old = [] {
+        const char* e = getenv("ESMK_GEMM");
+        return e != nullptr && strcmp(e, "old") == 0;
+    }();
+    if (!env_old && !p.force_old && !p.force_generic && !p.dbg && gemm8_supports(p, epi))
+        return launch_gemm8(p, epi, operand_dtype, st);
     if (operand_dtype == ESMK_DT_F16) return dispatch<_Float16>(p, epi, st);
     if (operand_dtype == ESMK_DT_BF16) return dispatch<__bf16>(p, epi, st);
     return hipErrorInvalidValue;

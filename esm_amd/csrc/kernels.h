@@ -24,6 +24,8 @@ struct GemmArgs {
     void* out = nullptr;
     int M = 0, N = 0, K = 0;
     int force_generic = 0;
+    int force_old = 0;  // use the one-tile-per-workgroup kernels of gemm.hip (A/B measurements, tests)
+    int panel_c = 0;    // gemm8: N tiles per column panel of the tile order (0 = choose)
     int dbg = 0;  // timing experiments only (tools/microbench.py): 1 no staging, 2 no barrier, 4 no LDS reads
     // EPI_QKV_ROPE only
     void* q = nullptr;   // [B,H,T,64]
@@ -36,6 +38,9 @@ struct GemmArgs {
 };
 
 hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st);
+// gemm8.hip: persistent ping-pong kernel (K % 64 == 0, N % 8 == 0); launch_gemm prefers it
+bool gemm8_supports(const GemmArgs& p, int epi);
+hipError_t launch_gemm8(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st);
 
 // ---- elementwise.hip -------------------------------------------------------------------
 // per-sequence statistics of the token matrix (esm2.py:82,86-92): scale[b] for token dropout,

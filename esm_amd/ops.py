@@ -31,7 +31,8 @@ def layernorm(x, gamma, beta, operand_dtype=torch.float16, want_op=True, want_f3
     return y, y32
 
 
-def linear(a, w, bias=None, epilogue=N.EPI_STORE_T, out=None, force_generic=False, dbg=0):
+def linear(a, w, bias=None, epilogue=N.EPI_STORE_T, out=None, force_generic=False, dbg=0, force_old=False,
+           panel_c=0):
     """nn.Linear with fused epilogue: a [M,K], w [N,K] (both f16 or bf16), bias fp32 [N]."""
     _req_cuda(a, w, bias, out)
     assert a.dtype == w.dtype and a.dtype in (torch.float16, torch.bfloat16)
@@ -43,7 +44,10 @@ def linear(a, w, bias=None, epilogue=N.EPI_STORE_T, out=None, force_generic=Fals
     elif out is None:
         odt = a.dtype if epilogue in (N.EPI_STORE_T, N.EPI_GELU_T) else torch.float32
         out = torch.empty((M, Nn), dtype=odt, device=a.device)
-    code = N.dtype_code(a.dtype) | (0x100 if force_generic else 0) | (dbg << 12)
+    # 0x100: generic 64x64 kernel, 0x200: one-tile-per-workgroup 256x256 kernel (gemm.hip) instead of the
+    # persistent kernel (gemm8.hip); bits 20..27: tile-order panel width of the persistent kernel
+    code = (N.dtype_code(a.dtype) | (0x100 if force_generic else 0) | (0x200 if force_old else 0) | (dbg << 12)
+            | (panel_c << 20))
     N.check(N.lib.esmk_op_linear(N.ptr(a), N.ptr(w), N.ptr(bias), N.ptr(out), M, Nn, K, epilogue, code,
                                  N.cur_stream()))
     return out

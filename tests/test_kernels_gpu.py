@@ -80,6 +80,44 @@ def test_linear_epilogues(ops, M, N, K, generic, dt):
     assert (acc - (resid + ref)).abs().max().item() < tol
 
 
+@pytest.mark.parametrize(
+    "M,N,K",
+    [
+        (8192, 2560, 1280),  # 320 tiles: workgroups walk 2 tiles, the K-tile stream crosses a tile seam
+        (2304, 1280, 192),   # odd number of K tiles (LDS buffer parity flips between tiles)
+        (512, 256, 64),      # a single K tile per tile
+        (300, 384, 256),     # M and N tails
+        (4224, 5120, 1280),  # panel order with 20 N tiles, M tail tile
+        (1024, 1288, 128),   # N % 8 == 0 only
+    ],
+)
+@pytest.mark.parametrize("dt", DT)
+def test_persistent_gemm_bit_exact_vs_tile_kernel(ops, M, N, K, dt):
+    """gemm8.hip (persistent, ping-pong) accumulates in the same order as the one-tile-per-workgroup
+    kernel of gemm.hip, so the two must agree BIT FOR BIT; repeated launches catch LDS-DMA races."""
+    from esm_amd import _native as nat
+
+    g = torch.Generator(device="cuda").manual_seed(7)
+    a = torch.randn(M, K, device="cuda", generator=g).to(dt)
+    w = (torch.randn(N, K, device="cuda", generator=g) * torch.linspace(0.5, 1.5, N, device="cuda")[:, None]).to(dt)
+    bias = torch.randn(N, device="cuda", generator=g)
+    ref = a.float() @ w.float().t() + bias
+    tol = 3e-5 * math.sqrt(K) * 4 + 1e-5
+    for epi in (nat.EPI_STORE_F32, nat.EPI_GELU_T, nat.EPI_STORE_T, nat.EPI_GELU_F32):
+        old = ops.linear(a, w, bias, epi, force_old=True)
+        for rep in range(3):
+            new = ops.linear(a, w, bias, epi, panel_c=(0, 4, 1)[rep])
+            assert torch.equal(new, old), (epi, rep, (new.float() - old.float()).abs().max().item())
+    new = ops.linear(a, w, bias, nat.EPI_STORE_F32)
+    assert (new - ref).abs().max().item() < tol
+    resid = torch.randn(M, N, device="cuda", generator=g)
+    acc_old, acc_new = resid.clone(), resid.clone()
+    ops.linear(a, w, bias, nat.EPI_RESID_F32, out=acc_old, force_old=True)
+    ops.linear(a, w, bias, nat.EPI_RESID_F32, out=acc_new)
+    assert torch.equal(acc_new, acc_old)
+    assert (acc_new - (resid + ref)).abs().max().item() < tol
+
+
 def _rope_ref(x, inv_freq):
     # reference esm/rotary_embedding.py:11-20,47-61 restated for [B,H,T,d]
     T = x.shape[-2]

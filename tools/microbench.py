@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
     ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--panels", action="store_true", help="sweep the tile-order panel width of the persistent GEMM")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
     T, E, H, F = 1024, 1280, 20, 5120
@@ -29,13 +30,17 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
     if not args.only or "gemm" in args.only:
-        for name, N, K, epi in [("qkv-like store", 3 * E, E, nat.EPI_STORE_T), ("out_proj resid", E, E, nat.EPI_RESID_F32),
+        for name, N, K, epi in [("qkv-like store", 2 * E, E, nat.EPI_STORE_T), ("out_proj resid", E, E, nat.EPI_RESID_F32),
                                 ("fc1 gelu", F, E, nat.EPI_GELU_T), ("fc1 store", F, E, nat.EPI_STORE_T),
                                 ("fc2 resid", E, F, nat.EPI_RESID_F32), ("fc2 store", E, F, nat.EPI_STORE_T)]:
             a = rnd(M, K).to(dt); w = (rnd(N, K) / math.sqrt(K)).to(dt); bias = rnd(N)
             out = torch.zeros(M, N, device="cuda") if epi == nat.EPI_RESID_F32 else None
-            ms = timeit(lambda: ops.linear(a, w, bias, epi, out=out), args.iters)
-            print(f"gemm {name:16s} M={M} N={N} K={K}: {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TFLOP/s", flush=True)
+            variants = [("persistent", dict()), ("tile-kernel", dict(force_old=True))]
+            if args.panels:
+                variants += [(f"persistent C={c}", dict(panel_c=c)) for c in (1, 2, 4, 5, 10, 20) if c <= (N + 255) // 256]
+            for vname, kw in variants:
+                ms = timeit(lambda: ops.linear(a, w, bias, epi, out=out, **kw), args.iters)
+                print(f"gemm {name:16s} {vname:18s} M={M} N={N} K={K}: {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TFLOP/s", flush=True)
             del a, w, out
     if "dbg" in args.only:
         N, K = E, F
