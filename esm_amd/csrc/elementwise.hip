@@ -110,44 +110,67 @@ hipError_t launch_embed(const int64_t* tokens, const float* table, const float* 
 // lane), two-pass mean / variance in fp32, 16-byte loads and 8/16-byte stores.
 // Algorithmic traffic per row: 4E read + 2E (operand dtype) and/or 4E (fp32) written.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NCH>
+// VAR (tools/microbench.py --only ln sweeps it; the engine uses LN_DEFAULT_VARIANT):
+//   bit 0: two rows per wave (both rows' loads in flight before the first reduction)
+//   bit 1: non-temporal stores (the normalised rows are consumed by the next kernel from HBM/MALL,
+//          not from this CU's cache)
+//   bit 2: non-temporal loads
+template <typename T, int NCH, int VAR>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
                                                          T* __restrict__ y, float* __restrict__ y32,
                                                          int rows, int E) {
+    constexpr int RPW = (VAR & 1) ? 2 : 1;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
     const int e4 = E >> 2;
-    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * E);
-    f32x4 v[NCH];
-    float s = 0.f;
+    f32x4 v[RPW][NCH];
+    float s[RPW];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < e4) {
-            v[i] = xr[c];
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        } else {
-            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    const float mean = wave_sum(s) / (float)E;
-    float q = 0.f;
+    for (int r = 0; r < RPW; ++r) {
+        const int row = min(row0 + r, rows - 1);
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * E);
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < e4) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = v[i][e] - mean;
-                q += d * d;
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < e4) {
+                if constexpr (VAR & 4) v[r][i] = __builtin_nontemporal_load(xr + c);
+                else v[r][i] = xr[c];
+            } else {
+                v[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     }
-    const float var = wave_sum(q) / (float)E;
-    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) t += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
+        s[r] = t;
+    }
+    float mean[RPW], rstd[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) mean[r] = wave_sum(s[r]) / (float)E;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < e4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[r][i][e] - mean[r];
+                    q += d * d;
+                }
+            }
+        }
+        s[r] = q;
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) rstd[r] = 1.0f / sqrtf(wave_sum(s[r]) / (float)E + 1e-5f);
     const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
     const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
 #pragma unroll
@@ -155,27 +178,43 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const int c = lane + 64 * i;
         if (c < e4) {
             const f32x4 g = g4[c], bb = b4[c];
-            f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + bb[e];
-            if (y) {
-                typename Op<T>::v4 p;
+            for (int r = 0; r < RPW; ++r) {
+                const int row = row0 + r;
+                if (row >= rows) continue;
+                f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) p[e] = Op<T>::from(o[e]);
-                *reinterpret_cast<typename Op<T>::v4*>(y + (size_t)row * E + c * 4) = p;
+                for (int e = 0; e < 4; ++e) o[e] = (v[r][i][e] - mean[r]) * rstd[r] * g[e] + bb[e];
+                if (y) {
+                    typename Op<T>::v4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = Op<T>::from(o[e]);
+                    auto* dst = reinterpret_cast<typename Op<T>::v4*>(y + (size_t)row * E + c * 4);
+                    if constexpr (VAR & 2) __builtin_nontemporal_store(pk, dst);
+                    else *dst = pk;
+                }
+                if (y32) {
+                    auto* dst = reinterpret_cast<f32x4*>(y32 + (size_t)row * E + c * 4);
+                    if constexpr (VAR & 2) __builtin_nontemporal_store(o, dst);
+                    else *dst = o;
+                }
             }
-            if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)row * E + c * 4) = o;
         }
     }
 }
 
-template <typename T>
-static hipError_t ln_dispatch(const float* x, const float* g, const float* b, void* y, float* y32,
-                              int rows, int E, hipStream_t st) {
-    const unsigned blocks = (unsigned)((rows + 3) / 4);
+// measured on MI355X, 65536 x 1280 rows (profiles/r1_v3_microbench.log): variant 0 3.65 TB/s,
+// 1 5.34, 3 5.57, 7 6.02 TB/s of algorithmic traffic
+constexpr int LN_DEFAULT_VARIANT = 7;
+
+template <typename T, int VAR>
+static hipError_t ln_dispatch_v(const float* x, const float* g, const float* b, void* y, float* y32,
+                                int rows, int E, hipStream_t st) {
+    constexpr int RPW = (VAR & 1) ? 2 : 1;
+    const unsigned blocks = (unsigned)((rows + 4 * RPW - 1) / (4 * RPW));
     T* yt = reinterpret_cast<T*>(y);
-#define ESMK_LN(N)                                                                              \
-    hipLaunchKernelGGL((layernorm_kernel<T, N>), dim3(blocks), dim3(256), 0, st, x, g, b, yt, y32, \
+#define ESMK_LN(N)                                                                                   \
+    hipLaunchKernelGGL((layernorm_kernel<T, N, VAR>), dim3(blocks), dim3(256), 0, st, x, g, b, yt, y32, \
                        rows, E)
     if (E <= 512) ESMK_LN(2);
     else if (E <= 1280) ESMK_LN(5);
@@ -186,11 +225,30 @@ static hipError_t ln_dispatch(const float* x, const float* g, const float* b, vo
     return hipGetLastError();
 }
 
+template <typename T>
+static hipError_t ln_dispatch(const float* x, const float* g, const float* b, void* y, float* y32,
+                              int rows, int E, int variant, hipStream_t st) {
+    switch (variant) {
+        case 0: return ln_dispatch_v<T, 0>(x, g, b, y, y32, rows, E, st);
+        case 1: return ln_dispatch_v<T, 1>(x, g, b, y, y32, rows, E, st);
+        case 2: return ln_dispatch_v<T, 2>(x, g, b, y, y32, rows, E, st);
+        case 3: return ln_dispatch_v<T, 3>(x, g, b, y, y32, rows, E, st);
+        case 6: return ln_dispatch_v<T, 6>(x, g, b, y, y32, rows, E, st);
+        case 7: return ln_dispatch_v<T, 7>(x, g, b, y, y32, rows, E, st);
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* y,
                             float* y32, int rows, int E, int operand_dtype, hipStream_t st) {
     if (E % 4 != 0 || rows <= 0) return hipErrorInvalidValue;
-    if (operand_dtype == ESMK_DT_BF16) return ln_dispatch<__bf16>(x, gamma, beta, y, y32, rows, E, st);
-    return ln_dispatch<_Float16>(x, gamma, beta, y, y32, rows, E, st);
+    // bits 8..11 of operand_dtype: kernel variant + 1 (micro-benchmarks); 0 = engine default
+    const int vsel = (operand_dtype >> 8) & 0xf;
+    const int variant = vsel ? vsel - 1 : LN_DEFAULT_VARIANT;
+    operand_dtype &= 0xff;
+    if (operand_dtype == ESMK_DT_BF16)
+        return ln_dispatch<__bf16>(x, gamma, beta, y, y32, rows, E, variant, st);
+    return ln_dispatch<_Float16>(x, gamma, beta, y, y32, rows, E, variant, st);
 }
 
 // ---------------------------------------------------------------------------------------------

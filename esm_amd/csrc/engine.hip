@@ -590,6 +590,11 @@ int esmk_op_linear(const void* a_dev, const void* w_dev, const float* bias_dev, 
     return 0;
 }
 
+int esmk_debug_gemm_timing(void* stamps_dev) {
+    gemm8_set_timing((unsigned long long*)stamps_dev);
+    return 0;
+}
+
 int esmk_op_qkv_rope(esmk_model* m, const void* a_dev, const void* wqkv_dev,
                      const float* bias_dev, void* q_out, void* k_out, void* vt_out, int B, int T,
                      void* stream) {

@@ -571,7 +571,7 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
         const char* e = getenv("ESMK_GEMM");
         return e != nullptr && strcmp(e, "old") == 0;
     }();
-    if (!env_old && !p.force_old && !p.force_generic && !p.dbg && gemm8_supports(p, epi))
+    if (!env_old && !p.force_old && !p.force_generic && gemm8_supports(p, epi))
         return launch_gemm8(p, epi, operand_dtype, st);
     if (operand_dtype == ESMK_DT_F16) return dispatch<_Float16>(p, epi, st);
     if (operand_dtype == ESMK_DT_BF16) return dispatch<__bf16>(p, epi, st);

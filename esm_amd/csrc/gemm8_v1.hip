@@ -1,3 +1,6 @@
+// gemm8_v1.hip — frozen copy of the first persistent GEMM (commit d2404fb), kept ONLY as an in-run
+// A/B reference for tools/microbench.py (box-to-box clock variance is larger than the deltas under study).
+// Not used by the engine.
 // gemm8.hip — persistent, ping-pong scheduled nn.Linear for gfx950:
 //     C[M,N] = A[M,K] . W[N,K]^T (+ bias, + fused epilogue)          K % 64 == 0, N % 8 == 0
 //
@@ -39,11 +42,9 @@
 //   waited for by ALL waves before a barrier that precedes its first read.
 #include "common.h"
 #include "kernels.h"
-#include <stdlib.h>
-#include <string.h>
-#include <type_traits>
 
 namespace esmk {
+namespace v1ref {
 
 constexpr int P_UNIT = 128 * 128;           // 16 KiB: 128 rows x 64 operand elements
 constexpr int P_BUF = 4 * P_UNIT;           // one K tile
@@ -56,19 +57,7 @@ ESMK_DEV void wg_barrier() {
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int N>
-ESMK_DEV void wait_vmcnt() {
-    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-ESMK_DEV void wait_vmcnt8() { wait_vmcnt<8>(); }
-
-// Global stores a full (unclipped) epilogue issues per wave: the first K tile after it may leave
-// them in flight, see the wait bookkeeping in gemm8_kernel.
-template <int EPI>
-constexpr int epilogue_stores() {
-    return (EPI == EPI_STORE_F32 || EPI == EPI_GELU_F32 || EPI == EPI_RESID_F32) ? 32 : 16;
-}
+ESMK_DEV void wait_vmcnt8() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 
 template <typename T>
 ESMK_DEV typename Op<T>::v4 pack4_(float a, float b, float c, float d) {
@@ -88,25 +77,20 @@ ESMK_DEV typename Op<T>::v4 pack4_(float a, float b, float c, float d) {
 //   EPI_V_T (MFMA A operand = activation rows):
 //     acc[j][i][r]:  n = n_base + 32 j + (lane & 31);  m = m_base + 32 i + 8 (r>>2) + 4 (lane>>5) + (r&3)
 // --------------------------------------------------------------------------------------------
-// The bias is already in the accumulators (gemm8_kernel starts every tile from acc = bias) except for
-// EPI_V_T, whose bias varies with the lane instead of the register.  FULL = the wave's block lies
-// completely inside [0,M) x [0,N): no store is predicated, so the wave issues exactly
-// epilogue_stores<EPI>() store instructions.
-template <typename T, int EPI, bool FULL, bool NOSTORE = false>
+template <typename T, int EPI>
 ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int n_base, int lane,
                         char* wl) {
     using V4 = typename Op<T>::v4;
     using V8 = typename Op<T>::v8;
     const int h = lane >> 5, lm = lane & 31;
-    if constexpr (!FULL)
-        if (n_base >= p.N || m_base >= p.M) return;  // wave uniform
+    if (n_base >= p.N || m_base >= p.M) return;  // wave uniform
 
     if constexpr (EPI == EPI_V_T) {
         // vt[b][head][dv][Tp], keys permuted inside groups of 16 (4-groups 1 and 2 swapped)
         const int head = n_base >> 6;
         T* vt = reinterpret_cast<T*>(p.vt);
         const float bv0 = p.bias[n_base + lm], bv1 = p.bias[n_base + 32 + lm];
-        const bool aligned = FULL || (p.T % 32 == 0);  // a 32-token piece = one aligned run of one sequence
+        const bool aligned = (p.T % 32 == 0);  // a 32-token piece = one aligned run of one sequence
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             // LDS piece: 64 rows (dv) x 64 B (32 tokens); 16-byte chunk c holds 8 token slots
@@ -126,7 +110,7 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
             }
             const int mp = m_base + 32 * i;
             if (aligned) {
-                if (FULL || mp < p.M) {
+                if (mp < p.M) {
                     const int b = mp / p.T, t0 = mp - b * p.T;
                     T* base = vt + ((size_t)(b * p.H + head) * 64) * p.Tp + t0;
                     V8 v[4];
@@ -165,6 +149,12 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
         const int head = (n_base - which * p.E) >> 6;
         T* qk = reinterpret_cast<T*>(which == 0 ? p.q : p.k);
         const float sc = which == 0 ? p.scaling : 1.0f;
+        f32x4 b1[4], b2[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            b1[g] = *reinterpret_cast<const f32x4*>(p.bias + n_base + 8 * g + 4 * h);
+            b2[g] = *reinterpret_cast<const f32x4*>(p.bias + n_base + 32 + 8 * g + 4 * h);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = min(m_base + 32 * i + lm, p.M - 1);
@@ -178,8 +168,8 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // bias, q scaling (mha.py:261), x*cos + rotate_half(x)*sin (rotary_embedding.py:11-20)
-                    const float a1 = acc[0][i][4 * g + e] * sc;
-                    const float a2 = acc[1][i][4 * g + e] * sc;
+                    const float a1 = (acc[0][i][4 * g + e] + b1[g][e]) * sc;
+                    const float a2 = (acc[1][i][4 * g + e] + b2[g][e]) * sc;
                     y1[e] = a1 * c[e] - a2 * s[e];
                     y2[e] = a2 * c[e] + a1 * s[e];
                 }
@@ -200,7 +190,7 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
                 const int pc = it * 64 + lane;
                 const int r = pc >> 3, cc = pc & 7;
                 const int mm = m_base + 32 * i + r;
-                if (FULL || mm < p.M) {
+                if (mm < p.M) {
                     const int b = mm / p.T, tt = mm - b * p.T;
                     *reinterpret_cast<V8*>(qk + ((size_t)(b * p.H + head) * p.T + tt) * 64 + cc * 8) = v[it];
                 }
@@ -208,6 +198,15 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
         }
     } else if constexpr (EPI == EPI_STORE_T || EPI == EPI_GELU_T) {
         T* out = reinterpret_cast<T*>(p.out);
+        f32x4 bv[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n_base + 32 * j + 8 * g + 4 * h;
+                bv[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias && n < p.N) bv[j][g] = *reinterpret_cast<const f32x4*>(p.bias + n);
+            }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -217,7 +216,7 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[j][i][4 * g + e];
+                        v[e] = acc[j][i][4 * g + e] + bv[j][g][e];
                         if constexpr (EPI == EPI_GELU_T) v[e] = gelu_fast(v[e]);
                     }
                     *reinterpret_cast<V4*>(wl + lm * 128 + (((4 * j + g) ^ (lm & 7)) << 4) + 8 * h) =
@@ -235,8 +234,7 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
                 const int pc = it * 64 + lane;
                 const int r = pc >> 3, cc = pc & 7;
                 const int m = m_base + 32 * i + r, n = n_base + cc * 8;
-                if constexpr (NOSTORE) asm volatile("" ::"v"(v[it]));
-                else if (FULL || (m < p.M && n < p.N)) *reinterpret_cast<V8*>(out + (size_t)m * p.N + n) = v[it];
+                if (m < p.M && n < p.N) *reinterpret_cast<V8*>(out + (size_t)m * p.N + n) = v[it];
             }
         }
     } else {
@@ -261,10 +259,13 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
                 if (piece + 1 < 8) load_old(nxt, piece + 1);  // residual of the next piece in flight
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                const int n = n_base + 32 * j + 8 * g + 4 * h;
+                f32x4 bvv = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias && n < p.N) bvv = *reinterpret_cast<const f32x4*>(p.bias + n);
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[j][i][4 * g + e];
+                    v[e] = acc[j][i][4 * g + e] + bvv[e];
                     if constexpr (EPI == EPI_GELU_F32) v[e] = gelu_fast(v[e]);
                 }
                 *reinterpret_cast<f32x4*>(wl + lm * 128 + (((2 * g + h) ^ (lm & 7)) << 4)) = v;
@@ -284,7 +285,7 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
                 if constexpr (EPI == EPI_RESID_F32)
                     v = f32x4{old[it][0] + v[0], old[it][1] + v[1], old[it][2] + v[2], old[it][3] + v[3]};
                 const int m = m_base + 32 * i + r, n = n_base + 32 * j + cc * 4;
-                if (FULL || (m < p.M && n < p.N)) *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
+                if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
             }
             if constexpr (EPI == EPI_RESID_F32) {
 #pragma unroll
@@ -297,18 +298,8 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
 // --------------------------------------------------------------------------------------------
 // kernel
 // --------------------------------------------------------------------------------------------
-// SCHED 0: fragment reads per load section 12 / 4 / 8 / 0.   SCHED 1: 4 / 4 / 8 / 8 — the (i0,i1)
-// activation fragments of the NEXT stream position are read in section L3 into their own registers.
-// DBG != 0 builds timing experiments (tools/microbench.py --only dbg8; results are wrong):
-//   bit 0 no MFMA, bit 1 no LDS-DMA, bit 2 no fragment reads, bit 3 no epilogue,
-//   bit 4 epilogue without its global stores, bit 5 leave a FULL epilogue's stores in flight behind the
-//   next K tile (vmcnt(8 + S) for its waits; measured slower than waiting), bit 6 every DMA re-reads
-//   K slab 0 (L2 resident).
-// PF > 0: every wave touches one dword of 64 of the 512 cache lines of stream position s + PF per K
-// tile (an L2 prefetch: the LDS-DMA of that position then hits the XCD's L2 instead of paying the
-// fabric / HBM latency inside the two-K-tile-deep DMA window).
-template <typename T, int EPI, int SCHED = 0, int DBG = 0, int PF = 0>
-__global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long long* timing) {
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V8 = typename Op<T>::v8;
     const int tid = threadIdx.x;
@@ -335,9 +326,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
         const int pnl = o / panel_full;
         const int rem = o - pnl * panel_full;
         const int w = min(panel_c, tiles_n - pnl * panel_c);
-        // (integer division runs on the VALU: pin the wave-uniform results back into SGPRs)
-        tmi = __builtin_amdgcn_readfirstlane(rem / w);
-        tni = __builtin_amdgcn_readfirstlane(pnl * panel_c + (rem - tmi * w));
+        tmi = rem / w;
+        tni = pnl * panel_c + (rem - tmi * w);
     };
 
     // ---- LDS-DMA streams -----------------------------------------------------------------------
@@ -371,15 +361,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
     };
     auto issue = [&](Stream& s, int unit, int buf) {
         char* dst = smem + buf * P_BUF + unit * P_UNIT + wave * 2048;
-        if constexpr (!(DBG & 2)) {
-            glds16(s.base + s.off0, dst);
-            glds16(s.base + s.off1, dst + 1024);
-        }
+        glds16(s.base + s.off0, dst);
+        glds16(s.base + s.off1, dst + 1024);
         // advance to the next stream position; past the end of the workgroup's tile list the last
         // K tile is re-issued (into a dead buffer) so the vmcnt bookkeeping stays uniform
         if (s.kt + 1 < nk) {
-            s.kt = __builtin_amdgcn_readfirstlane(s.kt + 1);
-            if constexpr (!(DBG & 64)) s.base += 128;
+            ++s.kt;
+            s.base += 128;
         } else if (s.it + 1 < n_my) {
             set_tile(s, unit, s.it + 1);
         }
@@ -397,45 +385,6 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
     issue(sA0, 0, 1);
     issue(sW0, 1, 1);
 
-    // ---- L2 prefetch stream (PF > 0): waves 0-3 cover the 256 A rows, waves 4-7 the 256 W rows ----
-    Stream sP;
-    unsigned pf_dummy = 0;  // destination of the prefetch loads; never read
-    auto set_tile_pf = [&](int it) {
-        int tmi, tni;
-        tile_coords(it, tmi, tni);
-        sP.it = it;
-        sP.kt = 0;
-        const int row = (wave & 3) * 64 + lane;
-        if (wave < 4) {
-            sP.base = reinterpret_cast<const char*>(p.A) + (size_t)tmi * 256 * row_bytes;
-            sP.off0 = (unsigned)min(row, p.M - tmi * 256 - 1) * row_bytes;
-        } else {
-            sP.base = reinterpret_cast<const char*>(p.W) + (size_t)tni * 256 * row_bytes;
-            sP.off0 = (unsigned)min(row, p.N - tni * 256 - 1) * row_bytes;
-        }
-    };
-    auto advance_pf = [&]() {
-        if (sP.kt + 1 < nk) {
-            sP.kt = __builtin_amdgcn_readfirstlane(sP.kt + 1);
-            sP.base += 128;
-        } else if (sP.it + 1 < n_my) {
-            set_tile_pf(sP.it + 1);
-        }
-    };
-    auto prefetch = [&]() {
-        if constexpr (PF > 0) {
-            // hipcc does not count an asm load: pf_dummy stays reserved ("+v" below) until a later counted
-            // wait has retired it (vmcnt is in order), and nothing ever consumes the value
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(pf_dummy) : "v"(sP.off0), "s"(sP.base) : "memory");
-            advance_pf();
-        }
-    };
-    if constexpr (PF > 0) {
-        set_tile_pf(0);
-#pragma unroll 1
-        for (int k = 0; k < PF; ++k) advance_pf();
-    }
-
     // ---- fragment read offsets -----------------------------------------------------------------
     const int lrow = (lane & 31) * 128;
     const int swz = (lane >> 1) & 7;
@@ -445,247 +394,89 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
     const int a_off = grp * (64 * 128) + lrow;
     const int w_off = wn * (32 * 128) + lrow;
 
-    V8 fa[2][4], fb[2][4], fw0[4], fw1[4];  // fb: (i2,i3) fragments, SCHED 1 only
+    V8 fa[2][4], fw0[4], fw1[4];
     f32x16 acc[2][4];
-    if constexpr (DBG & 4) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                fa[0][ks][e] = fa[1][ks][e] = fb[0][ks][e] = fb[1][ks][e] = Op<T>::from(0.f);
-                fw0[ks][e] = fw1[ks][e] = Op<T>::from(0.f);
-            }
-    }
 
-    auto rdA = [&](V8 (&f)[2][4], const char* ub) {
-        if constexpr (DBG & 4) return;
+    auto rdA = [&](const char* ub) {
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                f[i2][ks] = *reinterpret_cast<const V8*>(ub + a_off + i2 * 4096 + xo[ks]);
+                fa[i2][ks] = *reinterpret_cast<const V8*>(ub + a_off + i2 * 4096 + xo[ks]);
     };
     auto rdW = [&](V8 (&fw)[4], const char* ub) {
-        if constexpr (DBG & 4) return;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fw[ks] = *reinterpret_cast<const V8*>(ub + w_off + xo[ks]);
     };
     // one 64 x 32 quadrant over K = 64: 8 MFMAs, the two accumulators alternate
-    auto quad = [&](f32x16& c0, f32x16& c1, const V8 (&fw)[4], const V8 (&f)[2][4]) {
+    auto quad = [&](f32x16& c0, f32x16& c1, const V8 (&fw)[4]) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if constexpr (DBG & 1) {
-                asm volatile("" ::"v"(fw[ks]), "v"(f[0][ks]), "v"(f[1][ks]));
-            } else if constexpr (EPI == EPI_V_T) {  // lane owns 4 consecutive tokens of one channel
-                c0 = Op<T>::mma(f[0][ks], fw[ks], c0);
-                c1 = Op<T>::mma(f[1][ks], fw[ks], c1);
+            if constexpr (EPI == EPI_V_T) {  // lane owns 4 consecutive tokens of one channel
+                c0 = Op<T>::mma(fa[0][ks], fw[ks], c0);
+                c1 = Op<T>::mma(fa[1][ks], fw[ks], c1);
             } else {  // lane owns 4 consecutive channels of one token
-                c0 = Op<T>::mma(fw[ks], f[0][ks], c0);
-                c1 = Op<T>::mma(fw[ks], f[1][ks], c1);
+                c0 = Op<T>::mma(fw[ks], fa[0][ks], c0);
+                c1 = Op<T>::mma(fw[ks], fa[1][ks], c1);
             }
         }
         __builtin_amdgcn_s_setprio(0);
     };
 
-    int cur = 0;  // LDS buffer of the current stream position
-    // acc = bias (the nn.Linear bias rides through the K loop; fp32).  The wave's 64 bias values are
-    // fetched with SCALAR loads through the constant address space: they do not enter the vmcnt queue,
-    // so they neither wait for the LDS-DMA stream nor for the previous epilogue's stores.
-    typedef const __attribute__((address_space(4))) float* cfloat_ptr;
-    auto init_acc = [&](int n_base) {
-        bool done = false;
-        if constexpr (EPI != EPI_V_T) {
-            if (p.bias != nullptr) {
-                const int hsel = lane >> 5;
-                if (n_base + 64 <= p.N) {
-                    cfloat_ptr cb = (cfloat_ptr)(unsigned long long)(p.bias + n_base);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            // 8 SGPRs at a time (the whole row would pin 64 SGPRs next to the loop state)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float b0 = cb[32 * j + 8 * g + e], b1 = cb[32 * j + 8 * g + 4 + e];
-                                const float b = hsel ? b1 : b0;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) acc[j][i][4 * g + e] = b;
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                } else {  // N tail: clamped vector loads
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int n = n_base + 32 * j + 8 * g + 4 * hsel + e;
-                                const float b = n < p.N ? p.bias[n] : 0.f;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) acc[j][i][4 * g + e] = b;
-                            }
-                }
-                done = true;
-            }
-        }
-        if (!done) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-        }
-    };
+    wait_vmcnt8();  // U0, U1 of position 0 have landed
+    wg_barrier();
 
-    // One K tile = 4 phases.  WN = vmcnt immediate of the three counted waits: 8 in steady state
-    // (a unit is waited for 4 load sections = 8 DMA instructions after its issue), 8 + S for the first
-    // K tile after a FULL epilogue, whose S store instructions are younger than every DMA the tile
-    // waits for: they stay in flight behind the main loop instead of stalling it.
-    // EPI_RESID_F32: the epilogue reads the fp32 residual tile it adds to.  Its 8 pieces are latency
-    // bound on those loads (HBM miss ~2.5k cycles each), so at the end of the tile's LAST K tile every
-    // lane touches one dword of 4 of the wave's 256 residual cache lines: by the time the epilogue asks
-    // for them they sit in the XCD's L2.  Measured (profiles/r1_v4_*): fc2 (80 K tiles per tile) -3 %,
-    // out_proj (20 K tiles) +7 % because its epilogue burst is HBM-bandwidth bound, so it is only used for
-    // long K loops.  (DBG bit 7 switches it off for A/B runs.)
-    constexpr bool XPF = (EPI == EPI_RESID_F32) && !(DBG & 128);
-    unsigned x_dummy = 0;  // destination of those loads; never read
-    int m_base_cur = 0, n_base_cur = 0;
-    bool last_kt = false;
-    auto prefetch_x = [&]() {
-        if constexpr (XPF) {
-            const float* xo_ = reinterpret_cast<const float*>(p.out);
+    int cur = 0;
+    for (int it = 0; it < n_my; ++it) {
+        int tmi, tni;
+        tile_coords(it, tmi, tni);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int L = q * 64 + lane;
-                const int row = min(m_base_cur + (L >> 1), p.M - 1);
-                const int n = min(n_base_cur + (L & 1) * 32, p.N - 4);
-                const float* addr = xo_ + (size_t)row * p.N + n;
-                asm volatile("global_load_dword %0, %1, off" : "+v"(x_dummy) : "v"(addr) : "memory");
-            }
-        }
-    };
-    constexpr int S_EPI = epilogue_stores<EPI>();
-    constexpr int WBASE = PF > 0 ? 9 : 8;  // VM instructions a wave issues per K tile: 8 DMA (+ 1 prefetch)
-    bool young_stores = false;  // wave uniform: this K tile directly follows a FULL epilogue
-    auto wait_units = [&]() {
-        if ((DBG & 32) != 0 && young_stores) wait_vmcnt<WBASE + S_EPI>();
-        else wait_vmcnt<WBASE>();
-    };
-    auto ktile = [&]() {
-        const char* sb = smem + cur * P_BUF;
-        if constexpr (SCHED == 0) {
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+        if (grp == 1) wg_barrier();  // group 1 runs one section behind group 0
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* sb = smem + cur * P_BUF;
             // ---- phase 0 -----------------------------------------------------------------------
-            rdA(fa, sb);
+            rdA(sb);
             rdW(fw0, sb + P_UNIT);
             issue(sW1, 2, cur ^ 1);
-            wait_units();
+            wait_vmcnt8();
             wg_barrier();
-            quad(acc[0][0], acc[0][1], fw0, fa);
+            quad(acc[0][0], acc[0][1], fw0);
             wg_barrier();
             // ---- phase 1 -----------------------------------------------------------------------
             rdW(fw1, sb + 2 * P_UNIT);
             issue(sA1, 3, cur ^ 1);
-            wait_units();
+            wait_vmcnt8();
             wg_barrier();
-            quad(acc[1][0], acc[1][1], fw1, fa);
+            quad(acc[1][0], acc[1][1], fw1);
             wg_barrier();
             // ---- phase 2 -----------------------------------------------------------------------
-            rdA(fa, sb + 3 * P_UNIT);
+            rdA(sb + 3 * P_UNIT);
             issue(sA0, 0, cur);
             wg_barrier();
-            quad(acc[1][2], acc[1][3], fw1, fa);
+            quad(acc[1][2], acc[1][3], fw1);
             wg_barrier();
             // ---- phase 3 -----------------------------------------------------------------------
             issue(sW0, 1, cur);
-            wait_units();
-            if constexpr (PF > 0) asm volatile("" : "+v"(pf_dummy));  // the previous prefetch has retired
-            prefetch();
-            if constexpr (XPF)
-                if (last_kt && nk >= 40) prefetch_x();  // after the K tile's last counted wait
+            wait_vmcnt8();
             wg_barrier();
-            quad(acc[0][2], acc[0][3], fw0, fa);
+            quad(acc[0][2], acc[0][3], fw0);
             wg_barrier();
-        } else {
-            // fa = (i0,i1) fragments of this position, read in L3 of the previous position
-            rdW(fw0, sb + P_UNIT);
-            issue(sW1, 2, cur ^ 1);
-            wait_units();  // U2 of cur
-            wg_barrier();
-            quad(acc[0][0], acc[0][1], fw0, fa);
-            wg_barrier();
-            rdW(fw1, sb + 2 * P_UNIT);
-            issue(sA1, 3, cur ^ 1);
-            wait_units();  // U3 of cur
-            wg_barrier();
-            quad(acc[1][0], acc[1][1], fw1, fa);
-            wg_barrier();
-            rdA(fb, sb + 3 * P_UNIT);
-            issue(sA0, 0, cur);
-            wait_units();  // U0 of cur^1 (next position)
-            wg_barrier();
-            quad(acc[1][2], acc[1][3], fw1, fb);
-            wg_barrier();
-            rdA(fa, smem + (cur ^ 1) * P_BUF);
-            issue(sW0, 1, cur);
-            wait_units();  // U1 of cur^1
-            wg_barrier();
-            quad(acc[0][2], acc[0][3], fw0, fb);
-            wg_barrier();
-        }
-        cur ^= 1;
-    };
-
-    wait_vmcnt8();  // U0, U1 of position 0 have landed
-    wg_barrier();
-    if constexpr (SCHED == 1) rdA(fa, smem);
-    auto stamp = [&](int it, int k) {
-        if (timing != nullptr && tid == 0) {
-            unsigned long long* t = timing + ((size_t)blockIdx.x * 32 + (it & 31)) * 4;
-            t[k] = __builtin_readcyclecounter();
-            if (k == 2) t[3] = wall_clock64();  // constant-rate counter: ticks / wall gives the shader clock
-        }
-    };
-
-    for (int it = 0; it < n_my; ++it) {
-        int tmi, tni;
-        tile_coords(it, tmi, tni);
-        const int m_base = tmi * 256 + grp * 128, n_base = tni * 256 + wn * 64;
-        init_acc(n_base);
-        stamp(it, 0);
-
-        if (grp == 1) wg_barrier();  // group 1 runs one section behind group 0
-        m_base_cur = m_base;
-        n_base_cur = n_base;
-#pragma unroll 1
-        for (int kt = 0; kt < nk; ++kt) {
-            last_kt = (kt == nk - 1);
-            ktile();
-            young_stores = false;
+            cur ^= 1;
         }
         if (grp == 0) wg_barrier();  // re-align: both groups run the epilogue together
-        stamp(it, 1);
 
-        char* slice = smem + P_EPI + wave * P_SLICE;
-        if constexpr (DBG & 8) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[j][i]));
-        } else {
-            bool full = (m_base + 128 <= p.M) && (n_base + 64 <= p.N);
-            if constexpr (EPI == EPI_V_T) full = full && (p.T % 32 == 0);
-            if (full) epilogue8<T, EPI, true, (DBG & 16) != 0>(p, acc, m_base, n_base, lane, slice);
-            else epilogue8<T, EPI, false, (DBG & 16) != 0>(p, acc, m_base, n_base, lane, slice);
-            young_stores = full && !(DBG & 16);
-        }
-        if constexpr (XPF) asm volatile("" : "+v"(x_dummy));  // the epilogue's own loads retired them
-        stamp(it, 2);
+        epilogue8<T, EPI>(p, acc, tmi * 256 + grp * 128, tni * 256 + wn * 64, lane,
+                          smem + P_EPI + wave * P_SLICE);
     }
     wait_vmcnt0();  // the trailing (dummy) DMA writes must land before the LDS is released
-    if constexpr (PF > 0) asm volatile("" ::"v"(pf_dummy));
 }
 
 // --------------------------------------------------------------------------------------------
@@ -703,15 +494,10 @@ static int num_workgroups() {
     return n;
 }
 
-static unsigned long long* g_timing = nullptr;  // esmk_debug_gemm_timing()
-void gemm8_set_timing(unsigned long long* dev_buf) { g_timing = dev_buf; }
-
-constexpr int PF_DEFAULT = 0;
-
-template <typename T, int EPI, int SCHED = 0, int DBG = 0, int PF = PF_DEFAULT>
+template <typename T, int EPI>
 static hipError_t launch8(GemmArgs p, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = gemm8_kernel<T, EPI, SCHED, DBG, PF>;
+    auto kern = gemm8_kernel<T, EPI>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
@@ -727,96 +513,36 @@ static hipError_t launch8(GemmArgs p, hipStream_t st) {
         else if (tiles_n % 6 == 0) p.panel_c = 6;
         else p.panel_c = 5;
     }
-    hipLaunchKernelGGL(kern, dim3(num_workgroups()), dim3(512), P_LDS, st, p, g_timing);
+    hipLaunchKernelGGL(kern, dim3(num_workgroups()), dim3(512), P_LDS, st, p);
     return hipGetLastError();
-}
-
-namespace v1ref {
-hipError_t launch_gemm8_v1(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st);
-}
-static hipError_t v1ref_launch(const GemmArgs& p, int epi, int dt, hipStream_t st) {
-    GemmArgs q = p;
-    q.dbg = 0;
-    return v1ref::launch_gemm8_v1(q, epi, dt, st);
 }
 
 template <typename T>
 static hipError_t dispatch8(const GemmArgs& p, int epi, hipStream_t st) {
-    if (p.dbg == 0xff) return v1ref_launch(p, epi, std::is_same<T, _Float16>::value ? ESMK_DT_F16 : ESMK_DT_BF16, st);
-    if (p.dbg) {  // timing experiments and schedule A/B (tools/microbench.py)
-        if constexpr (std::is_same<T, _Float16>::value) {
-            if (epi == EPI_STORE_T) {
-                switch (p.dbg) {
-                    case 0x10: return launch8<T, EPI_STORE_T, 1, 0>(p, st);
-                    case 0x01: return launch8<T, EPI_STORE_T, 0, 1>(p, st);
-                    case 0x02: return launch8<T, EPI_STORE_T, 0, 2>(p, st);
-                    case 0x04: return launch8<T, EPI_STORE_T, 0, 4>(p, st);
-                    case 0x08: return launch8<T, EPI_STORE_T, 0, 8>(p, st);
-                    case 0x06: return launch8<T, EPI_STORE_T, 0, 6>(p, st);
-                    case 0x07: return launch8<T, EPI_STORE_T, 0, 7>(p, st);
-                    case 0x0e: return launch8<T, EPI_STORE_T, 0, 14>(p, st);
-                    case 0x18: return launch8<T, EPI_STORE_T, 1, 8>(p, st);
-                    case 0x20: return launch8<T, EPI_STORE_T, 0, 16>(p, st);
-                    case 0x40: return launch8<T, EPI_STORE_T, 0, 32>(p, st);
-                    case 0x60: return launch8<T, EPI_STORE_T, 0, 64>(p, st);
-                    case 0x68: return launch8<T, EPI_STORE_T, 0, 64 + 8>(p, st);
-                    case 0x82: return launch8<T, EPI_STORE_T, 0, 0, 2>(p, st);
-                    case 0x83: return launch8<T, EPI_STORE_T, 0, 0, 3>(p, st);
-                    case 0x84: return launch8<T, EPI_STORE_T, 0, 0, 4>(p, st);
-                    case 0x86: return launch8<T, EPI_STORE_T, 0, 0, 6>(p, st);
-                    case 0x8c: return launch8<T, EPI_STORE_T, 0, 8, 4>(p, st);
-                }
-            }
-            if (p.dbg == 0x90 && epi == EPI_RESID_F32) return launch8<T, EPI_RESID_F32, 0, 128>(p, st);
-            if (p.dbg == 0x84) {
-                if (epi == EPI_GELU_T) return launch8<T, EPI_GELU_T, 0, 0, 4>(p, st);
-                if (epi == EPI_RESID_F32) return launch8<T, EPI_RESID_F32, 0, 0, 4>(p, st);
-            }
-        }
-        return hipErrorInvalidValue;
+    switch (epi) {
+        case EPI_STORE_T: return launch8<T, EPI_STORE_T>(p, st);
+        case EPI_STORE_F32: return launch8<T, EPI_STORE_F32>(p, st);
+        case EPI_GELU_T: return launch8<T, EPI_GELU_T>(p, st);
+        case EPI_GELU_F32: return launch8<T, EPI_GELU_F32>(p, st);
+        case EPI_RESID_F32: return launch8<T, EPI_RESID_F32>(p, st);
+        case EPI_QKV_ROPE: return launch8<T, EPI_QKV_ROPE>(p, st);
+        case EPI_V_T: return launch8<T, EPI_V_T>(p, st);
     }
-    // ESMK_GEMM8_MODE (read once): engine-level A/B of kernel variants with bench.py
-    static const int mode = [] {
-        const char* e = getenv("ESMK_GEMM8_MODE");
-        if (e == nullptr) return 0;
-        if (!strcmp(e, "v1")) return 1;
-        if (!strcmp(e, "pf4")) return 2;
-        if (!strcmp(e, "young")) return 3;
-        if (!strcmp(e, "noxpf")) return 4;
-        return 0;
-    }();
-    if (mode == 1) return v1ref_launch(p, epi, std::is_same<T, _Float16>::value ? ESMK_DT_F16 : ESMK_DT_BF16, st);
-#define ESMK_CASES(SC, DB, PFD)                                                   \
-    switch (epi) {                                                                \
-        case EPI_STORE_T: return launch8<T, EPI_STORE_T, SC, DB, PFD>(p, st);     \
-        case EPI_STORE_F32: return launch8<T, EPI_STORE_F32, SC, DB, PFD>(p, st); \
-        case EPI_GELU_T: return launch8<T, EPI_GELU_T, SC, DB, PFD>(p, st);       \
-        case EPI_GELU_F32: return launch8<T, EPI_GELU_F32, SC, DB, PFD>(p, st);   \
-        case EPI_RESID_F32: return launch8<T, EPI_RESID_F32, SC, DB, PFD>(p, st); \
-        case EPI_QKV_ROPE: return launch8<T, EPI_QKV_ROPE, SC, DB, PFD>(p, st);   \
-        case EPI_V_T: return launch8<T, EPI_V_T, SC, DB, PFD>(p, st);             \
-    }
-    if constexpr (std::is_same<T, _Float16>::value) {
-        if (mode == 2) { ESMK_CASES(0, 0, 4) }
-        if (mode == 3) { ESMK_CASES(0, 32, 0) }
-        if (mode == 4) { ESMK_CASES(0, 128, 0) }
-    }
-    ESMK_CASES(0, 0, PF_DEFAULT)
-#undef ESMK_CASES
     return hipErrorInvalidValue;
 }
 
-bool gemm8_supports(const GemmArgs& p, int epi) {
+bool gemm8_supports_v1(const GemmArgs& p, int epi) {
     if (p.K % 64 != 0 || p.N % 8 != 0 || p.M <= 0) return false;
     if ((epi == EPI_QKV_ROPE || epi == EPI_V_T) && p.N % 64 != 0) return false;
     return true;
 }
 
-hipError_t launch_gemm8(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st) {
-    if (!gemm8_supports(p, epi)) return hipErrorInvalidValue;
+hipError_t launch_gemm8_v1(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st) {
+    if (!gemm8_supports_v1(p, epi)) return hipErrorInvalidValue;
     if (operand_dtype == ESMK_DT_F16) return dispatch8<_Float16>(p, epi, st);
     if (operand_dtype == ESMK_DT_BF16) return dispatch8<__bf16>(p, epi, st);
     return hipErrorInvalidValue;
 }
 
+}  // namespace v1ref
 }  // namespace esmk

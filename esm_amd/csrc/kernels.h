@@ -41,6 +41,8 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
 // gemm8.hip: persistent ping-pong kernel (K % 64 == 0, N % 8 == 0); launch_gemm prefers it
 bool gemm8_supports(const GemmArgs& p, int epi);
 hipError_t launch_gemm8(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st);
+// measurement hook: per-tile s_memtime stamps of workgroup-leader lanes ([workgroup][tile & 31][4])
+void gemm8_set_timing(unsigned long long* dev_buf);
 
 // ---- elementwise.hip -------------------------------------------------------------------
 // per-sequence statistics of the token matrix (esm2.py:82,86-92): scale[b] for token dropout,

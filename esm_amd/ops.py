@@ -19,15 +19,16 @@ def _req_cuda(*ts):
             raise RuntimeError("esm_amd.ops: tensors must be contiguous")
 
 
-def layernorm(x, gamma, beta, operand_dtype=torch.float16, want_op=True, want_f32=False):
+def layernorm(x, gamma, beta, operand_dtype=torch.float16, want_op=True, want_f32=False, variant=None):
     """torch.nn.LayerNorm(E, eps=1e-5) on fp32 rows (reference esm/modules.py:68-81)."""
     _req_cuda(x, gamma, beta)
     assert x.dtype == torch.float32 and gamma.dtype == torch.float32 and beta.dtype == torch.float32
     rows, E = x.reshape(-1, x.shape[-1]).shape
     y = torch.empty_like(x, dtype=operand_dtype) if want_op else None
     y32 = torch.empty_like(x) if want_f32 else None
+    code = N.dtype_code(operand_dtype) | (0 if variant is None else (variant + 1) << 8)
     N.check(N.lib.esmk_op_layernorm(N.ptr(x), N.ptr(gamma), N.ptr(beta), N.ptr(y), N.ptr(y32), rows, E,
-                                    N.dtype_code(operand_dtype), N.cur_stream()))
+                                    code, N.cur_stream()))
     return y, y32
 
 

@@ -126,6 +126,11 @@ int esmk_op_layernorm(const float* x_dev, const float* gamma_dev, const float* b
 int esmk_op_linear(const void* a_dev, const void* w_dev, const float* bias_dev, void* out_dev,
                    int M, int N, int K, int epilogue, int operand_dtype, void* stream);
 
+/* Measurement hook (no reference counterpart): when stamps_dev != NULL every following persistent
+ * GEMM launch records s_memtime stamps per workgroup and tile, uint64 [256][32][4] =
+ * {tile start, main loop done, epilogue done, unused}; NULL switches it off. */
+int esmk_debug_gemm_timing(void* stamps_dev);
+
 /* Fused q/k/v projection + scaling + rotary + head split (multihead_attention.py:256-284,
  * :354-355; rotary_embedding.py:11-20).  a [B*T,E]; wqkv [3E,E]; bias [3E];
  * q_out,k_out [B,H,T,64]; vt_out [B,H,64,Tp] (V transposed, keys permuted in groups of 16,

@@ -93,8 +93,10 @@ def test_linear_epilogues(ops, M, N, K, generic, dt):
 )
 @pytest.mark.parametrize("dt", DT)
 def test_persistent_gemm_bit_exact_vs_tile_kernel(ops, M, N, K, dt):
-    """gemm8.hip (persistent, ping-pong) accumulates in the same order as the one-tile-per-workgroup
-    kernel of gemm.hip, so the two must agree BIT FOR BIT; repeated launches catch LDS-DMA races."""
+    """gemm8.hip (persistent, ping-pong) accumulates the K products in the same order as the
+    one-tile-per-workgroup kernel of gemm.hip, so without a bias the two must agree BIT FOR BIT
+    (with a bias gemm8 starts from acc = bias instead of adding it last: compared with a tolerance);
+    repeated launches with different tile orders catch LDS-DMA races."""
     from esm_amd import _native as nat
 
     g = torch.Generator(device="cuda").manual_seed(7)
@@ -104,17 +106,21 @@ def test_persistent_gemm_bit_exact_vs_tile_kernel(ops, M, N, K, dt):
     ref = a.float() @ w.float().t() + bias
     tol = 3e-5 * math.sqrt(K) * 4 + 1e-5
     for epi in (nat.EPI_STORE_F32, nat.EPI_GELU_T, nat.EPI_STORE_T, nat.EPI_GELU_F32):
-        old = ops.linear(a, w, bias, epi, force_old=True)
+        old = ops.linear(a, w, None, epi, force_old=True)
         for rep in range(3):
-            new = ops.linear(a, w, bias, epi, panel_c=(0, 4, 1)[rep])
+            new = ops.linear(a, w, None, epi, panel_c=(0, 4, 1)[rep])
             assert torch.equal(new, old), (epi, rep, (new.float() - old.float()).abs().max().item())
     new = ops.linear(a, w, bias, nat.EPI_STORE_F32)
     assert (new - ref).abs().max().item() < tol
+    new = ops.linear(a, w, bias, nat.EPI_GELU_T)
+    assert (new.float() - _gelu(ref)).abs().max().item() < tol + _eps(dt) * ref.abs().max().item()
     resid = torch.randn(M, N, device="cuda", generator=g)
     acc_old, acc_new = resid.clone(), resid.clone()
-    ops.linear(a, w, bias, nat.EPI_RESID_F32, out=acc_old, force_old=True)
-    ops.linear(a, w, bias, nat.EPI_RESID_F32, out=acc_new)
+    ops.linear(a, w, None, nat.EPI_RESID_F32, out=acc_old, force_old=True)
+    ops.linear(a, w, None, nat.EPI_RESID_F32, out=acc_new)
     assert torch.equal(acc_new, acc_old)
+    acc_new = resid.clone()
+    ops.linear(a, w, bias, nat.EPI_RESID_F32, out=acc_new)
     assert (acc_new - (resid + ref)).abs().max().item() < tol
 
 

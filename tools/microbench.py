@@ -42,15 +42,52 @@ def main():
                 ms = timeit(lambda: ops.linear(a, w, bias, epi, out=out, **kw), args.iters)
                 print(f"gemm {name:16s} {vname:18s} M={M} N={N} K={K}: {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TFLOP/s", flush=True)
             del a, w, out
-    if "dbg" in args.only:
-        N, K = E, F
-        a = rnd(M, K).to(dt); w = (rnd(N, K) / math.sqrt(K)).to(dt); bias = rnd(N)
-        for dbg, what in [(0, "full 2+1+1+0"), (1, "no staging"), (3, "no staging, no barrier"), (2, "staging, no wait/barrier"),
-                          (5, "MFMA + barrier only"), (7, "MFMA only"), (8, "staging only"), (24, "staging only, linear src"),
-                          (16, "full, linear src"), (40, "staging only, L2-resident slab"), (32, "full 2+1+1, L2-resident slab"),
-                          (64, "full, burst 4+0+0+0"), (128, "full, 2+2+0+0"), (96, "burst, L2-resident"), (160, "2+2, L2-resident")]:
-            ms = timeit(lambda: ops.linear(a, w, bias, nat.EPI_STORE_T, dbg=dbg), args.iters)
-            print(f"fc2-shape dbg={dbg} ({what}): {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TFLOP/s", flush=True)
+    if "dbg8" in args.only:
+        # timing experiments on the persistent GEMM (results are wrong for most dbg codes)
+        import ctypes
+        def stamps(fn, ntiles, nk):
+            buf = torch.zeros(256 * 32 * 4, dtype=torch.int64, device="cuda")
+            nat.check(nat.lib.esmk_debug_gemm_timing(ctypes.c_void_p(buf.data_ptr())))
+            fn(); torch.cuda.synchronize()
+            nat.check(nat.lib.esmk_debug_gemm_timing(ctypes.c_void_p(0)))
+            full = buf.view(256, 32, 4)[:, :ntiles, :].double().cpu()
+            t = full[:, :, :3]
+            wall = (full[:, -1, 3] - full[:, 0, 3])  # 100 MHz ticks between the first and the last epilogue end
+            cyc = (t[:, -1, 2] - t[:, 0, 2])
+            ghz = (cyc / wall.clamp(min=1)).mean().item() * 0.1 if ntiles > 1 else float("nan")
+            loop = (t[:, :, 1] - t[:, :, 0]).mean().item() / nk
+            epi = (t[:, :, 2] - t[:, :, 1]).mean().item()
+            gap = (t[:, 1:, 0] - t[:, :-1, 2]).mean().item() if ntiles > 1 else 0.0
+            tot = (t[:, -1, 2] - t[:, 0, 0]).mean().item()
+            first = (t[:, 0, 1] - t[:, 0, 0]).mean().item() / nk
+            totmax = (t[:, -1, 2] - t[:, 0, 0]).max().item()
+            return (f"cycles: {loop:7.1f}/K-tile (first tile {first:7.1f}), epilogue {epi:8.0f}, seam {gap:7.0f}, "
+                    f"total mean {tot:9.0f} max {totmax:9.0f}, shader clock {ghz:5.2f} GHz")
+        for name, N, K in [("fc2 shape", E, F), ("fc1 shape", F, E)]:
+            a = rnd(M, K).to(dt); w = (rnd(N, K) / math.sqrt(K)).to(dt); bias = rnd(N)
+            ntiles, nk = (M // 256) * (N // 256) // 256, K // 64
+            for dbg, what in [(0, "full"), (0xff, "v1 reference (commit d2404fb)"), (0x82, "L2 prefetch +2"), (0x83, "L2 prefetch +3"),
+                              (0x84, "L2 prefetch +4"), (0x86, "L2 prefetch +6"), (0x60, "DMA re-reads K slab 0"), (0x08, "no epilogue"),
+                              (0x8c, "prefetch +4, no epilogue"), (0x68, "slab 0, no epilogue"), (0x20, "epilogue w/o global stores"),
+                              (0x40, "young stores in flight"), (0x01, "no MFMA"), (0x02, "no LDS-DMA"), (0x04, "no fragment reads"),
+                              (0x06, "no DMA, no reads"), (0x0e, "MFMA + barriers only")]:
+                fn = lambda: ops.linear(a, w, bias, nat.EPI_STORE_T, dbg=dbg)
+                ms = timeit(fn, args.iters)
+                extra = stamps(fn, ntiles, nk) if dbg in (0, 0x84, 0x60, 0x08, 0x0e) else ""
+                print(f"gemm8 {name} dbg={dbg:#04x} ({what:30s}): {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TFLOP/s  {extra}", flush=True)
+            del a, w
+        for name, N, K, epi in [("fc1 gelu", F, E, nat.EPI_GELU_T), ("fc2 resid", E, F, nat.EPI_RESID_F32), ("out resid", E, E, nat.EPI_RESID_F32)]:
+            a = rnd(M, K).to(dt); w = (rnd(N, K) / math.sqrt(K)).to(dt); bias = rnd(N)
+            out = torch.zeros(M, N, device="cuda") if epi == nat.EPI_RESID_F32 else None
+            ntiles, nk = (M // 256) * (N // 256) // 256, K // 64
+            for dbg, what in ((0, "default"), (0x90, "no residual prefetch"), (0xff, "v1 reference")):
+                if dbg == 0x90 and epi != nat.EPI_RESID_F32:
+                    continue
+                fn = lambda: ops.linear(a, w, bias, epi, out=out, dbg=dbg)
+                ms = timeit(fn, args.iters)
+                extra = stamps(fn, ntiles, nk) if dbg != 0xff else ""
+                print(f"gemm8 {name} {what:16s}: {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TFLOP/s  {extra}", flush=True)
+            del a, w, out
     if not args.only or "qkv" in args.only:
         hnd = ops.QkvHandle(E, H, dt)
         a = rnd(M, E).to(dt); w = (rnd(3 * E, E) / math.sqrt(E)).to(dt); bias = rnd(3 * E)
@@ -63,8 +100,9 @@ def main():
         print(f"attention B={args.B} H={H} T={T}: {ms*1e3:8.1f} us  {4*args.B*H*T*T*64/ms/1e9:7.1f} TFLOP/s", flush=True)
     if not args.only or "ln" in args.only:
         x = rnd(M, E); gm = rnd(E); bt = rnd(E)
-        ms = timeit(lambda: ops.layernorm(x, gm, bt, dt), args.iters)
-        print(f"layernorm rows={M} E={E}: {ms*1e3:8.1f} us  {M*E*6/ms/1e6:7.1f} GB/s (6E B/row)", flush=True)
+        for var in (0, 1, 2, 3, 6, 7):
+            ms = timeit(lambda: ops.layernorm(x, gm, bt, dt, variant=var), args.iters)
+            print(f"layernorm variant {var} rows={M} E={E}: {ms*1e3:8.1f} us  {M*E*6/ms/1e6:7.1f} GB/s (6E B/row)", flush=True)
 
 
 if __name__ == "__main__":
