@@ -1,0 +1,25 @@
+#!/bin/bash
+# rocprofv3 passes over a short bench.py run (run on the GPU box through gpurun):
+#   1. kernel trace + stats            -> per-kernel durations
+#   2-4. PMC passes (kernel trace only, one counter group per pass, as the microarch guide prescribes)
+# usage: tools/profile_bench.sh <outdir-under-gpurun_out>
+set -u
+OUT=gpurun_out/${1:-prof}
+mkdir -p $OUT
+export TMPDIR=/tmp
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $CMD > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- $CMD > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o bench -- $CMD > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o bench -- $CMD > $OUT/pmc_sq.log 2>&1
+for d in trace; do
+  db=$(ls $OUT/$d/*/*_results.db $OUT/$d/*_results.db 2>/dev/null | head -1)
+  [ -n "$db" ] && python tools/rocpd_summary.py $db > $OUT/kernel_stats.md 2>&1
+done
+python tools/rocpd_pmc.py $(ls $OUT/pmc_*/*/*_results.db $OUT/pmc_*/*_results.db 2>/dev/null) > $OUT/pmc_summary.txt 2>&1
+ls -R $OUT | head -40 > $OUT/files.txt
+# the raw traces are large: keep only the summaries
+find $OUT -name "*.db" -size +20M -delete
+tail -3 $OUT/*.log
+cat $OUT/kernel_stats.md | head -30
+cat $OUT/pmc_summary.txt | head -30
