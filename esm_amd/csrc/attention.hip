@@ -9,8 +9,12 @@
 //
 // attn_fwd_kernel: one workgroup = 4 waves = 128 query rows of one (batch, head); each wave
 // owns 32 query rows.  K / V^T tiles of 64 keys are staged HBM->LDS by global_load_lds_dwordx4
-// (double buffered, 128-byte rows, 16-byte chunks XOR-swizzled with (row>>1)&7 on the source
-// address and on the read, so every ds_read_b128 is bank-conflict free).
+// (double buffered; a three-buffer variant with a counted vmcnt exists as template STAGES=3 and measured
+// 6 % slower; 128-byte rows, 16-byte chunks XOR-swizzled with (row>>1)&7 on the source address and on
+// the read, so every ds_read_b128 is bank-conflict free).
+// The 1-D grid is mapped so that all query blocks of one (batch, head) run on ONE XCD (workgroup id
+// % 8): its K / V^T (2 x T x 128 B) is fetched into that XCD's L2 once instead of once per XCD
+// (rocprofv3 FETCH_SIZE showed 5.5x the algorithmic bytes with the row-major grid).
 //   S^T = K . Q^T  is computed "swapped" (MFMA A operand = K rows, B operand = Q rows): lane l
 //   then holds, for query l&31, the scores of keys (r&3)+8(r>>2)+4(l>>5) — a full softmax row
 //   lives in two lanes (l, l^32), so row max / row sum need one cross-lane exchange per tile.
@@ -27,26 +31,53 @@
 #include "common.h"
 #include "kernels.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace esmk {
 
 constexpr float LOG2E = 1.4426950408889634f;
+// measured end to end in one run (profiles/r1_v6_attention_variants.log): variant 0 16.39 ms/step,
+// 1 (XCD-grouped grid) 16.14, 2 (three stages) 17.45, 4 (split reductions) 16.64, 7 (all) 17.44
+constexpr int ATTN_DEFAULT_VARIANT = 1;
 constexpr int A_TILE = 64 * 128;  // bytes of one K (or V^T) tile: 64 rows x 128 B
 constexpr int A_STAGE = 2 * A_TILE + 256;  // K + V^T + 64 fp32 key-bias values
 
-template <typename T>
+ESMK_DEV void attn_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    // lgkmcnt(0): this wave's LDS writes (key-bias row, epilogue staging) are complete when others pass
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// STAGES: LDS buffers of the K / V^T stream (2: one tile in flight, drained every tile; 3: two tiles in
+// flight behind a counted vmcnt).  TREE: 4-way split max / sum reductions.  xcdmap: see the file header.
+template <typename T, int STAGES, int TREE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
     const float* __restrict__ key_bias, const int* __restrict__ seq_info, T* __restrict__ ctx,
-    float* __restrict__ lse, int H, int Tlen, int Tp) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * A_STAGE];
+    float* __restrict__ lse, int H, int BH, int nq, int Tlen, int Tp, int xcdmap) {
+    __shared__ __attribute__((aligned(16))) char smem[STAGES * A_STAGE];
     using V8 = typename Op<T>::v8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, lm = lane & 31;
-    const int bh = blockIdx.y;
+    // workgroup id -> (batch*head, query block): ids with equal id % 8 (one XCD) share bh
+    int bh, qblk;
+    {
+        const int id = blockIdx.x;
+        const int bh8 = xcdmap ? (BH & ~7) : 0;  // heads covered by the XCD-grouped part of the grid
+        if (id < bh8 * nq) {
+            const int r = id >> 3;
+            qblk = r % nq;
+            bh = (r / nq) * 8 + (id & 7);
+        } else {
+            const int r = id - bh8 * nq;
+            bh = bh8 + r / nq;
+            qblk = r % nq;
+        }
+    }
     const int b = bh / H, head = bh - b * H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = qblk * 128 + wave * 32;
 
     // padding information of this sequence (wave uniform)
     int kv_end = Tlen;
@@ -119,14 +150,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     float m2 = -INFINITY;  // running max in the log2 domain (score * log2 e)
     float lsum = 0.f;      // this lane's share of the running denominator
 
+    // prologue: tile 0 (and 1) in flight
     if (ntiles > 0) stage(0, 0);
-    wait_vmcnt0();
-    __syncthreads();
+    if constexpr (STAGES == 3) {
+        if (ntiles > 1) stage(1, 1);
+    } else {
+        wait_vmcnt0();
+        __syncthreads();
+    }
 
+    int cur = 0;
     for (int kt = 0; kt < ntiles; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < ntiles) stage(cur ^ 1, kt + 1);
         const char* sk = smem + cur * A_STAGE;
+        if constexpr (STAGES == 3) {
+            // tile kt has landed (tile kt+1 may stay in flight); the barrier also tells every wave that
+            // buffer (kt+2)%3 == (kt-1)%3 is no longer read, so tile kt+2 can be staged into it
+            if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            attn_barrier();
+            if (kt + 2 < ntiles) stage(cur == 0 ? 2 : cur - 1, kt + 2);
+            cur = (cur == 2) ? 0 : cur + 1;
+        } else {
+            if (kt + 1 < ntiles) stage(cur ^ 1, kt + 1);
+            cur ^= 1;
+        }
         const char* sv = sk + A_TILE;
         const float* sb = reinterpret_cast<const float*>(sk + 2 * A_TILE);
 
@@ -154,17 +201,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
                 }
         }
         // ---- online softmax (fp32) ---------------------------------------------------------
-        float mx = st[0][0];
+        float mx;
+        if constexpr (TREE) {
+            float mx4[4];  // four independent chains instead of one 32-deep dependency chain
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
+            for (int c = 0; c < 4; ++c) mx4[c] = st[c >> 1][8 * (c & 1)];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t2][r]);
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 1; r < 8; ++r) mx4[c] = fmaxf(mx4[c], st[c >> 1][8 * (c & 1) + r]);
+            mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
+        } else {
+            mx = st[0][0];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t2][r]);
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m2, mx * LOG2E);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m2 - m_use);
         m2 = m_new;
-        float ps = 0.f;
+        float ps4[4] = {0.f, 0.f, 0.f, 0.f};
         V8 pf[4];
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
@@ -173,11 +232,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float p = __builtin_amdgcn_exp2f(st[t2][8 * ks + e] * LOG2E - m_use);
-                    ps += p;
+                    ps4[TREE ? 2 * t2 + ks : 0] += p;
                     pf[2 * t2 + ks][e] = Op<T>::from(p);
                 }
             }
-        lsum = lsum * alpha + ps;
+        lsum = lsum * alpha + ((ps4[0] + ps4[1]) + (ps4[2] + ps4[3]));
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -190,9 +249,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
                 const V8 vf = *reinterpret_cast<const V8*>(sv + d * 4096 + lrow + xo[kk]);
                 o[d] = Op<T>::mma(vf, pf[kk], o[d]);
             }
-        wait_vmcnt0();
-        __syncthreads();
+        if constexpr (STAGES == 2) {
+            wait_vmcnt0();
+            __syncthreads();
+        }
     }
+    if constexpr (STAGES == 3) attn_barrier();  // every wave is done with the K / V^T buffers
 
     // ---- normalise and store ctx[b*T + q][head*64 + dv] ---------------------------------------
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
@@ -228,15 +290,30 @@ hipError_t launch_attention(const void* q, const void* k, const void* vt, const 
                             const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
                             int operand_dtype, hipStream_t st) {
     if (B <= 0 || H <= 0 || T <= 0 || Tp < T || (Tp & 63)) return hipErrorInvalidValue;
-    dim3 grid((T + 127) / 128, B * H);
-    if (operand_dtype == ESMK_DT_BF16)
-        hipLaunchKernelGGL((attn_fwd_kernel<__bf16>), grid, dim3(256), 0, st, (const __bf16*)q,
-                           (const __bf16*)k, (const __bf16*)vt, key_bias, seq_info, (__bf16*)ctx, lse,
-                           H, T, Tp);
-    else
-        hipLaunchKernelGGL((attn_fwd_kernel<_Float16>), grid, dim3(256), 0, st, (const _Float16*)q,
-                           (const _Float16*)k, (const _Float16*)vt, key_bias, seq_info,
-                           (_Float16*)ctx, lse, H, T, Tp);
+    const int nq = (T + 127) / 128;
+    dim3 grid(nq * B * H);
+    // ESMK_ATTN (read once): bit 0 XCD-grouped grid, bit 1 three LDS stages, bit 2 split reductions
+    static const int var = [] {
+        const char* e = getenv("ESMK_ATTN");
+        return e ? atoi(e) : ATTN_DEFAULT_VARIANT;
+    }();
+#define ESMK_ATTN_LAUNCH(TT, ST, TR)                                                                    \
+    hipLaunchKernelGGL((attn_fwd_kernel<TT, ST, TR>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k, \
+                       (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1)
+#define ESMK_ATTN_VARIANTS(TT)                                   \
+    switch ((var >> 1) & 3) {                                    \
+        case 0: ESMK_ATTN_LAUNCH(TT, 2, 0); break;               \
+        case 1: ESMK_ATTN_LAUNCH(TT, 3, 0); break;               \
+        case 2: ESMK_ATTN_LAUNCH(TT, 2, 1); break;               \
+        default: ESMK_ATTN_LAUNCH(TT, 3, 1); break;              \
+    }
+    if (operand_dtype == ESMK_DT_BF16) {
+        ESMK_ATTN_VARIANTS(__bf16)
+    } else {
+        ESMK_ATTN_VARIANTS(_Float16)
+    }
+#undef ESMK_ATTN_VARIANTS
+#undef ESMK_ATTN_LAUNCH
     return hipGetLastError();
 }
 
