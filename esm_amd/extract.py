@@ -1,0 +1,205 @@
+"""Bulk FASTA embedding extraction, sharded over the GPUs of one node.
+
+Mirrors the reference driver ``scripts/extract.py`` (arguments, batching, the per-sequence ``.pt`` result
+files: reference scripts/extract.py:15-131) and adds the data-parallel split of SURVEY.md §8 e:
+
+* sequences are independent units, so there is no exchange step in the math: weights are replicated, the
+  length-sorted token-budget batches of ``FastaBatchedDataset.get_batch_indices`` (reference
+  esm/data.py:65-88) are assigned to ranks by longest-processing-time on the algorithmic cost
+  ``B*T*(24 E^2 + 4 T E)`` per layer, each rank writes the result files of its own sequences;
+* the only collectives (RCCL over xGMI on the GPUs, gloo in the CPU tests) are the scatter/gather the
+  north star names: an all-gather of the fixed-size mean embeddings so that rank 0 can return / write
+  one ``[n_sequences, E]`` matrix per layer in FASTA order.
+
+    python -m esm_amd.extract model.pt seqs.fasta out/ --repr_layers 33 --include mean per_tok
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+        -m esm_amd.extract model.pt seqs.fasta out/ --repr_layers 33 --include mean
+
+The model forward is ``esm_amd.ESM2`` on the MI355X (no CPU fallback); ``embed_fn`` exists so that the
+sharding / gather logic can be exercised by the world_size-2 gloo tests without a GPU.
+"""
+import argparse
+import os
+import pathlib
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+
+
+def batch_cost(n_seqs: int, width: int, embed_dim: int) -> float:
+    """Algorithmic FLOPs of one layer on a padded batch (SURVEY.md §8 a: 24 E^2 + 4 T E per token)."""
+    return float(n_seqs) * width * (24.0 * embed_dim * embed_dim + 4.0 * width * embed_dim)
+
+
+def assign_batches(batches: Sequence[Sequence[int]], lengths: Sequence[int], world: int, embed_dim: int,
+                   extra_toks: int = 2) -> List[List[int]]:
+    """Longest-processing-time assignment of batches (lists of sequence indices) to ``world`` ranks.
+    Returns, per rank, the list of batch ids in the order they should run (largest first).
+    Deterministic: ties are broken by batch id and rank id, so every rank computes the same plan."""
+    costs = []
+    for bid, b in enumerate(batches):
+        width = max(lengths[i] for i in b) + extra_toks
+        costs.append((batch_cost(len(b), width, embed_dim), bid))
+    order = sorted(costs, key=lambda c: (-c[0], c[1]))
+    load = [0.0] * world
+    plan: List[List[int]] = [[] for _ in range(world)]
+    for cost, bid in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        plan[r].append(bid)
+        load[r] += cost
+    return plan
+
+
+def _dist_info():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def gather_rows(local_rows: torch.Tensor, local_index: torch.Tensor, n_total: int) -> Optional[torch.Tensor]:
+    """All-gather of fixed-width rows: every rank contributes ``local_rows [n_i, W]`` for the global
+    row ids ``local_index [n_i]``; returns the ``[n_total, W]`` matrix (on every rank).  Counts differ
+    between ranks, so rows are padded to the maximum count before the (equal-size) all_gather."""
+    dist, rank, world = _dist_info()
+    W = local_rows.shape[1]
+    if world == 1:
+        out = local_rows.new_zeros((n_total, W))
+        out[local_index] = local_rows
+        return out
+    dev = local_rows.device
+    n_local = torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local)
+    n_max = int(max(c.item() for c in counts))
+    pad_rows = local_rows.new_zeros((n_max, W))
+    pad_rows[: local_rows.shape[0]] = local_rows
+    pad_idx = torch.full((n_max,), -1, dtype=torch.int64, device=dev)
+    pad_idx[: local_index.shape[0]] = local_index.to(dev)
+    all_rows = [torch.empty_like(pad_rows) for _ in range(world)]
+    all_idx = [torch.empty_like(pad_idx) for _ in range(world)]
+    dist.all_gather(all_rows, pad_rows)
+    dist.all_gather(all_idx, pad_idx)
+    out = local_rows.new_zeros((n_total, W))
+    for rows, idx, c in zip(all_rows, all_idx, counts):
+        n = int(c.item())
+        out[idx[:n]] = rows[:n]
+    return out
+
+
+def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool], Dict], num_layers: int,
+            embed_dim: int, repr_layers: Sequence[int], include: Sequence[str],
+            output_dir: Optional[pathlib.Path] = None, toks_per_batch: int = 4096,
+            truncation_seq_length: int = 1022, device: Optional[torch.device] = None,
+            gather_mean: bool = True, log: Callable[[str], None] = print):
+    """Run the sharded extraction.  ``embed_fn(tokens, repr_layers, return_contacts)`` is the model
+    forward (``ESM2.__call__`` in production).  Returns ``{layer: [n_sequences, E] mean embeddings}``
+    in dataset order when ``gather_mean`` (every rank gets the full matrix), else ``{}``."""
+    dist, rank, world = _dist_info()
+    assert all(-(num_layers + 1) <= i <= num_layers for i in repr_layers)
+    layers = [(i + num_layers + 1) % (num_layers + 1) for i in repr_layers]
+    return_contacts = "contacts" in include
+    lengths = [min(len(s), truncation_seq_length) for s in dataset.sequence_strs]
+    batches = dataset.get_batch_indices(toks_per_batch, extra_toks_per_seq=1)
+    plan = assign_batches(batches, lengths, world, embed_dim)
+    convert = alphabet.get_batch_converter(truncation_seq_length)
+    if output_dir is not None:
+        output_dir.mkdir(parents=True, exist_ok=True)
+
+    my_index: List[int] = []
+    my_means: Dict[int, List[torch.Tensor]] = {l: [] for l in layers}
+    with torch.no_grad():
+        for n_done, bid in enumerate(plan[rank]):
+            ids = batches[bid]
+            labels, strs, toks = convert([dataset[i] for i in ids])
+            log(f"[rank {rank}] batch {n_done + 1}/{len(plan[rank])}: {toks.size(0)} sequences x {toks.size(1)} tokens")
+            if device is not None:
+                toks = toks.to(device=device, non_blocking=True)
+            out = embed_fn(toks, layers, return_contacts)
+            reps = {l: t for l, t in out["representations"].items()}
+            for row, (seq_id, label) in enumerate(zip(ids, labels)):
+                n = min(truncation_seq_length, len(strs[row]))
+                result = {"label": label}
+                if "per_tok" in include:
+                    result["representations"] = {l: t[row, 1:n + 1].to("cpu").clone() for l, t in reps.items()}
+                means = {l: t[row, 1:n + 1].float().mean(0) for l, t in reps.items()}
+                if "mean" in include:
+                    result["mean_representations"] = {l: m.to("cpu").clone() for l, m in means.items()}
+                if "bos" in include:
+                    result["bos_representations"] = {l: t[row, 0].to("cpu").clone() for l, t in reps.items()}
+                if return_contacts:
+                    result["contacts"] = out["contacts"][row, :n, :n].to("cpu").clone()
+                if output_dir is not None:
+                    path = output_dir / f"{label}.pt"
+                    path.parent.mkdir(parents=True, exist_ok=True)
+                    torch.save(result, path)
+                my_index.append(seq_id)
+                for l in layers:
+                    my_means[l].append(means[l])
+    gathered: Dict[int, torch.Tensor] = {}
+    if gather_mean:
+        dev = device if device is not None else torch.device("cpu")
+        idx = torch.tensor(my_index, dtype=torch.int64, device=dev)
+        for l in layers:
+            rows = (torch.stack(my_means[l]) if my_means[l] else torch.zeros((0, embed_dim))).to(dev).float()
+            gathered[l] = gather_rows(rows.reshape(-1, embed_dim), idx, len(dataset))
+    return gathered
+
+
+def create_parser():
+    p = argparse.ArgumentParser(description="Sharded per-token / mean representation extraction on MI355X GPUs")
+    p.add_argument("model_location", type=str)
+    p.add_argument("fasta_file", type=pathlib.Path)
+    p.add_argument("output_dir", type=pathlib.Path)
+    p.add_argument("--toks_per_batch", type=int, default=4096)
+    p.add_argument("--repr_layers", type=int, default=[-1], nargs="+")
+    p.add_argument("--include", type=str, nargs="+", choices=["mean", "per_tok", "bos", "contacts"], required=True)
+    p.add_argument("--truncation_seq_length", type=int, default=1022)
+    p.add_argument("--mean_matrix", type=pathlib.Path, default=None,
+                   help="rank 0 also writes {layer: [n_sequences, E]} gathered mean embeddings to this file")
+    return p
+
+
+def main(argv=None):
+    args = create_parser().parse_args(argv)
+    from . import FastaBatchedDataset, pretrained
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("esm_amd.extract needs an MI355X: the engine has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+    model, alphabet = pretrained.load_model_and_alphabet(args.model_location)
+    model = model.eval().to(dev)
+    dataset = FastaBatchedDataset.from_file(args.fasta_file)
+    if rank == 0:
+        print(f"Read {args.fasta_file} with {len(dataset)} sequences; {world} rank(s)")
+
+    def embed_fn(toks, layers, return_contacts):
+        return model(toks, repr_layers=layers, return_contacts=return_contacts)
+
+    means = extract(dataset, alphabet, embed_fn, model.num_layers, model.embed_dim, args.repr_layers, args.include,
+                    output_dir=args.output_dir, toks_per_batch=args.toks_per_batch,
+                    truncation_seq_length=args.truncation_seq_length, device=dev,
+                    gather_mean=args.mean_matrix is not None)
+    if args.mean_matrix is not None and rank == 0:
+        torch.save({"labels": dataset.sequence_labels, "mean_representations": {l: t.cpu() for l, t in means.items()}},
+                   args.mean_matrix)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

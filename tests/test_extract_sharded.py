@@ -1,0 +1,101 @@
+"""Sharded bulk extraction (SURVEY.md §8 e): the batch plan, the LPT assignment and the RCCL/gloo
+gather are host logic and run on CPU; the model forward is replaced by a deterministic stub here (the
+real forward is covered on the MI355X by tests/test_model_gpu.py)."""
+import os
+import pathlib
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from esm_amd import Alphabet, FastaBatchedDataset  # noqa: E402
+from esm_amd.extract import assign_batches, batch_cost, extract  # noqa: E402
+
+E = 16
+LENGTHS = [428, 222, 502, 156, 80, 71, 99, 602, 127, 152, 98, 935, 102, 882, 659]  # some_proteins.fasta
+
+
+def _dataset():
+    g = torch.Generator().manual_seed(5)
+    aas = "LAGVSERTIDPKQNFYMHWC"
+    seqs = ["".join(aas[i] for i in torch.randint(0, 20, (n,), generator=g).tolist()) for n in LENGTHS]
+    return FastaBatchedDataset([f"seq{i}" for i in range(len(seqs))], seqs)
+
+
+def _stub_embed(toks, layers, return_contacts):
+    """representation[l][b,t,:] = token id * (l+1) + channel index: depends only on the sequence."""
+    ch = torch.arange(E, dtype=torch.float32)
+    reps = {l: toks[:, :, None].float() * (l + 1) + ch for l in layers}
+    out = {"representations": reps, "logits": torch.zeros(toks.shape + (33,))}
+    if return_contacts:
+        T = toks.shape[1]
+        out["contacts"] = torch.zeros((toks.shape[0], T - 2, T - 2))
+    return out
+
+
+def _expected_means(ds, alphabet, layer):
+    rows = []
+    for _, s in ds:
+        ids = torch.tensor(alphabet.encode(s), dtype=torch.float32)
+        rows.append((ids[:, None] * (layer + 1) + torch.arange(E, dtype=torch.float32)).mean(0))
+    return torch.stack(rows)
+
+
+def test_assign_batches_covers_everything_and_balances():
+    ds = _dataset()
+    batches = ds.get_batch_indices(1024, extra_toks_per_seq=1)
+    # golden: the reference's batching of these lengths (SURVEY.md §8 c)
+    assert batches == [[5, 4, 10, 6, 12, 8], [9, 3, 1], [0, 2], [7], [14], [13], [11]]
+    for world in (1, 2, 3, 8):
+        plan = assign_batches(batches, LENGTHS, world, 1280)
+        flat = sorted(b for r in plan for b in r)
+        assert flat == list(range(len(batches)))  # every batch exactly once
+        assert plan == assign_batches(batches, LENGTHS, world, 1280)  # deterministic
+        cost = lambda bid: batch_cost(len(batches[bid]), max(LENGTHS[i] for i in batches[bid]) + 2, 1280)
+        loads = [sum(cost(b) for b in r) for r in plan]
+        biggest = max(cost(b) for b in range(len(batches)))
+        assert max(loads) - min(loads) <= biggest + 1e-6  # LPT bound
+
+
+def test_single_process_extract_matches_reference_file_format(tmp_path):
+    ds = _dataset()
+    alphabet = Alphabet.from_architecture("ESM-1b")
+    means = extract(ds, alphabet, _stub_embed, num_layers=6, embed_dim=E, repr_layers=[-1, 0], include=["mean", "per_tok", "bos"],
+                    output_dir=tmp_path, toks_per_batch=1024, log=lambda s: None)
+    assert sorted(means) == [0, 6]
+    assert torch.allclose(means[6], _expected_means(ds, alphabet, 6))
+    r = torch.load(tmp_path / "seq3.pt")
+    assert r["label"] == "seq3"
+    assert r["representations"][6].shape == (LENGTHS[3], E)
+    assert torch.allclose(r["mean_representations"][0], means[0][3])
+    assert r["bos_representations"][6].shape == (E,)
+
+
+def _worker(rank, world, port, tmp):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ds = _dataset()
+        alphabet = Alphabet.from_architecture("ESM-1b")
+        means = extract(ds, alphabet, _stub_embed, num_layers=6, embed_dim=E, repr_layers=[6], include=["mean"],
+                        output_dir=pathlib.Path(tmp), toks_per_batch=1024, log=lambda s: None)
+        exp = _expected_means(ds, alphabet, 6)
+        assert torch.allclose(means[6], exp), f"rank {rank}: gathered means differ"
+        dist.barrier()
+        if rank == 0:
+            files = sorted(p.name for p in pathlib.Path(tmp).glob("*.pt"))
+            assert files == sorted(f"seq{i}.pt" for i in range(len(ds)))  # every sequence written exactly once
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_extract_gloo(tmp_path, world):
+    port = 29600 + world + (os.getpid() % 200)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
