@@ -114,3 +114,84 @@ def write_esm2_checkpoint(directory, name, num_layers, embed_dim, heads, seed=0,
     torch.save({"cfg": {"model": cfg}, "model": body}, path)
     torch.save({"model": regression}, os.path.join(directory, name + "-contact-regression.pt"))
     return path
+
+
+# ---------------------------------------------------------------------------------------------------
+# MSA Transformer (reference esm/model/msa_transformer.py:88-144)
+# ---------------------------------------------------------------------------------------------------
+MSA_DIMS = {
+    # name: (layers, embed_dim, heads, ffn)                               
+    "esm_msa1b_t12_100M_UR50S": (12, 768, 12, 3072),
+}
+
+
+def msa_param_shapes(num_layers, embed_dim, heads, ffn_dim, max_positions=1024, vocab=33, padding_idx=1):
+    """State-dict keys and shapes of MSATransformer with embed_positions_msa=True."""
+    E, F = embed_dim, ffn_dim
+    shapes = {"msa_position_embedding": (1, 1024, 1, E), "embed_tokens.weight": (vocab, E)}
+    for i in range(num_layers):
+        for blk in ("row_self_attention", "column_self_attention"):
+            p = f"layers.{i}.{blk}."
+            for proj in ("k_proj", "v_proj", "q_proj", "out_proj"):
+                shapes[p + f"layer.{proj}.weight"] = (E, E)
+                shapes[p + f"layer.{proj}.bias"] = (E,)
+            shapes[p + "layer_norm.weight"] = (E,)
+            shapes[p + "layer_norm.bias"] = (E,)
+        p = f"layers.{i}.feed_forward_layer."
+        shapes[p + "layer.fc1.weight"] = (F, E)
+        shapes[p + "layer.fc1.bias"] = (F,)
+        shapes[p + "layer.fc2.weight"] = (E, F)
+        shapes[p + "layer.fc2.bias"] = (E,)
+        shapes[p + "layer_norm.weight"] = (E,)
+        shapes[p + "layer_norm.bias"] = (E,)
+    shapes["contact_head.regression.weight"] = (1, num_layers * heads)
+    shapes["contact_head.regression.bias"] = (1,)
+    shapes["embed_positions.weight"] = (max_positions + padding_idx + 1, E)
+    for k in ("emb_layer_norm_before", "emb_layer_norm_after", "lm_head.layer_norm"):
+        shapes[k + ".weight"] = (E,)
+        shapes[k + ".bias"] = (E,)
+    shapes["lm_head.weight"] = (vocab, E)
+    shapes["lm_head.bias"] = (vocab,)
+    shapes["lm_head.dense.weight"] = (E, E)
+    shapes["lm_head.dense.bias"] = (E,)
+    return shapes
+
+
+def synth_msa_state_dict(num_layers, embed_dim, heads, ffn_dim, seed=0, qk_gain=2.0, device="cpu", max_positions=1024):
+    """fp32 MSA-Transformer state dict with the reference's key names."""
+    sd = {}
+    for key, shape in msa_param_shapes(num_layers, embed_dim, heads, ffn_dim, max_positions).items():
+        if key == "lm_head.weight":
+            continue
+        if key == "embed_tokens.weight":
+            sd[key] = _draw(key, shape, seed, 0.25, device=device)
+        elif key == "embed_positions.weight":
+            sd[key] = _draw(key, shape, seed, 0.1, device=device)
+            sd[key][1] = 0.0  # padding_idx row of nn.Embedding
+        elif key == "msa_position_embedding":
+            sd[key] = _draw(key, shape, seed, 0.1, device=device)
+        elif key.startswith("contact_head.regression.weight"):
+            sd[key] = _draw(key, shape, seed, 4.0, device=device)
+        elif key.startswith("contact_head.regression.bias"):
+            sd[key] = _draw(key, shape, seed, 0.5, mean=-1.0, device=device)
+        elif "layer_norm" in key and key.endswith(".weight"):
+            sd[key] = _draw(key, shape, seed, 0.02, mean=1.0, device=device)
+        elif len(shape) == 2:
+            gain = qk_gain if (".q_proj." in key or ".k_proj." in key) else 1.0
+            sd[key] = _draw(key, shape, seed, 0.02 * (1280.0 / shape[1]) ** 0.5 * gain, device=device)
+        else:
+            sd[key] = _draw(key, shape, seed, 0.02, device=device)
+    sd["lm_head.weight"] = sd["embed_tokens.weight"]
+    return sd
+
+
+def synth_msa_tokens(batch, rows, cols, seed=1, gap_frac=0.05, device="cpu"):
+    """BASELINE config 5 input: column 0 = <cls>, the rest uniform over the 20 amino acids with
+    ``gap_frac`` '-' (id 30) tokens, no pads (SURVEY.md §8 d)."""
+    g = torch.Generator()
+    g.manual_seed(seed)
+    toks = torch.randint(4, 24, (batch, rows, cols), generator=g, dtype=torch.int64)
+    gaps = torch.rand((batch, rows, cols), generator=g) < gap_frac
+    toks[gaps] = 30
+    toks[:, :, 0] = 0
+    return toks.to(device)

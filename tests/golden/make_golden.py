@@ -27,6 +27,27 @@ CASES = {
 }
 
 
+MSA_CASES = {
+    # name: dims, seed, MSA shape [B,R,C]; pads: a shorter row and a fully padded trailing column block
+    "tiny_d64": dict(L=2, E=128, H=2, F=256, seed=21, B=2, R=5, C=19, pads=True),
+    "mid_d64": dict(L=2, E=192, H=3, F=384, seed=22, B=1, R=12, C=70, pads=False),
+    "onerow_d64": dict(L=1, E=128, H=2, F=256, seed=23, B=1, R=1, C=33, pads=False),
+}
+
+
+def build_msa_tokens(B, R, C, seed, pads):
+    g = torch.Generator().manual_seed(seed)
+    toks = torch.randint(4, 24, (B, R, C), generator=g, dtype=torch.int64)
+    toks[torch.rand((B, R, C), generator=g) < 0.08] = 30  # gaps
+    toks[:, :, 0] = 0
+    if pads:
+        toks[0, :, C - 3:] = 1      # MSA 0 is 3 columns shorter (batch padding)
+        toks[0, 2, 4] = 32          # a <mask>
+        if B > 1:
+            toks[1, R - 1, :] = 1   # MSA 1 has one row less (batch padding in depth)
+    return toks
+
+
 def build_tokens(B, T, seed, nopad=False):
     g = torch.Generator().manual_seed(seed)
     toks = torch.randint(4, 24, (B, T), generator=g, dtype=torch.int64)
@@ -85,5 +106,47 @@ def main():
         print(name, "->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def main_msa():
+    import argparse
+
+    sys.path.insert(0, ROOT)
+    from esm_amd.synth import synth_msa_state_dict
+
+    sys.path.insert(0, REFERENCE)
+    for k in [k for k in sys.modules if k == "esm" or k.startswith("esm.")]:
+        del sys.modules[k]
+    ref = importlib.import_module("esm")
+    assert ref.__file__.startswith(REFERENCE), ref.__file__
+    alphabet = ref.Alphabet.from_architecture("msa_transformer")
+    for name, c in MSA_CASES.items():
+        sd = synth_msa_state_dict(c["L"], c["E"], c["H"], c["F"], seed=c["seed"])
+        args = argparse.Namespace(layers=c["L"], embed_dim=c["E"], ffn_embed_dim=c["F"], attention_heads=c["H"],
+                                  dropout=0.1, attention_dropout=0.1, activation_dropout=0.1, max_positions=1024,
+                                  embed_positions_msa=True, embed_positions_msa_dim=c["E"], max_tokens=2 ** 14,
+                                  max_tokens_per_msa=2 ** 14)
+        model = ref.MSATransformer(args, alphabet).eval()
+        model.load_state_dict(sd, strict=True)
+        toks = build_msa_tokens(c["B"], c["R"], c["C"], c["seed"], c["pads"])
+        with torch.no_grad():
+            out = model(toks, repr_layers=list(range(c["L"] + 1)), return_contacts=True)
+        fix = {
+            "dims": {k: c[k] for k in ("L", "E", "H", "F", "seed")},
+            "tokens": toks,
+            "weights_checksum": float(sum(v.double().sum() for k, v in sd.items() if k != "lm_head.weight")),
+            "logits": out["logits"].float(),
+            "representations": {k: v.float() for k, v in out["representations"].items()},
+            "row_attentions": out["row_attentions"].float(),
+            "col_attentions": out["col_attentions"].float(),
+            "contacts": out["contacts"].float(),
+            "reference_version": getattr(ref, "__version__", "?"),
+            "torch_version": torch.__version__,
+        }
+        path = os.path.join(HERE, f"msa_{name}.pt")
+        torch.save(fix, path)
+        print(name, "->", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    main()
+    if "--msa-only" not in sys.argv:
+        main()
+    main_msa()
