@@ -34,6 +34,12 @@ class EsmkConfig(ctypes.Structure):
     ]
 
 
+class EsmkMsaConfig(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in (
+        "num_layers", "embed_dim", "num_heads", "ffn_dim", "vocab", "pad_idx", "mask_idx", "cls_idx", "eos_idx",
+        "prepend_bos", "append_eos", "num_positions", "has_msa_position_embedding", "operand_dtype")]
+
+
 class EsmkProfileEntry(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 32), ("launches", c_int32), ("ms", ctypes.c_double),
                 ("flops", ctypes.c_double), ("bytes", ctypes.c_double)]
@@ -56,6 +62,17 @@ SIGNATURES = {
         c_int,
         [
             c_void_p, c_void_p, c_void_p, c_int, c_int,
+            POINTER(c_int32), c_int, POINTER(c_void_p),
+            c_uint32, c_void_p, c_void_p, c_void_p,
+            c_void_p, c_size_t, c_void_p,
+        ],
+    ),
+    "esmk_msa_create": (c_int, [POINTER(EsmkMsaConfig), POINTER(c_void_p)]),
+    "esmk_msa_workspace_bytes": (c_int, [c_void_p, c_int, c_int, c_int, c_uint32, POINTER(c_size_t)]),
+    "esmk_msa_forward": (
+        c_int,
+        [
+            c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
             POINTER(c_int32), c_int, POINTER(c_void_p),
             c_uint32, c_void_p, c_void_p, c_void_p,
             c_void_p, c_size_t, c_void_p,

@@ -55,7 +55,8 @@ template <typename T, int STAGES, int TREE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
     const float* __restrict__ key_bias, const int* __restrict__ seq_info, T* __restrict__ ctx,
-    float* __restrict__ lse, int H, int BH, int nq, int Tlen, int Tp, int xcdmap) {
+    float* __restrict__ lse, int H, int BH, int nq, int Tlen, int Tp, int xcdmap, int fill_mode,
+    const int* __restrict__ any_pad) {
     __shared__ __attribute__((aligned(16))) char smem[STAGES * A_STAGE];
     using V8 = typename Op<T>::v8;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -82,7 +83,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     // padding information of this sequence (wave uniform)
     int kv_end = Tlen;
     bool use_mask = (Tlen & 63) != 0;
-    if (key_bias != nullptr) {
+    if (fill_mode) {
+        // MSA column attention: key_bias holds 0/1 fill flags, used only when the batch has a pad
+        if (key_bias != nullptr && any_pad != nullptr && any_pad[0] != 0) use_mask = true;
+        else key_bias = nullptr;
+    } else if (key_bias != nullptr) {
         if (seq_info != nullptr) {
             if (seq_info[2 * b] > 0) {  // sequence has pads: mask them, skip all-pad tail tiles
                 use_mask = true;
@@ -130,8 +135,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
         }
         if (use_mask && tid < 64) {
             const int key = k0 + tid;
-            float bv = -INFINITY;
-            if (key < Tlen) bv = key_bias ? key_bias[(size_t)b * Tlen + key] : 0.f;
+            float bv = -INFINITY;  // keys past the end of the row: excluded
+            if (key < Tlen) {
+                bv = key_bias ? key_bias[(size_t)b * Tlen + key] : 0.f;
+                // fill flag -> +inf marker: the score is REPLACED by -10000 (masked_fill, axial_attention.py:211-215)
+                if (fill_mode) bv = (bv != 0.f) ? INFINITY : 0.f;
+            }
             reinterpret_cast<float*>(base + 2 * A_TILE)[tid] = bv;
         }
     };
@@ -197,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(sb + t2 * 32 + 8 * g + 4 * h);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) st[t2][4 * g + e] += bv[e];
+                    for (int e = 0; e < 4; ++e)
+                        st[t2][4 * g + e] = (bv[e] == INFINITY) ? -10000.f : st[t2][4 * g + e] + bv[e];
                 }
         }
         // ---- online softmax (fp32) ---------------------------------------------------------
@@ -286,9 +296,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
         lse[(size_t)bh * Tlen + qrow] = m2 * (1.0f / LOG2E) + logf(ltot);
 }
 
+static hipError_t launch_attention_impl(const void* q, const void* k, const void* vt, const float* key_bias,
+                                        const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
+                                        int operand_dtype, int fill_mode, const int* any_pad, hipStream_t st);
+
 hipError_t launch_attention(const void* q, const void* k, const void* vt, const float* key_bias,
                             const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
                             int operand_dtype, hipStream_t st) {
+    return launch_attention_impl(q, k, vt, key_bias, seq_info, ctx, lse, B, H, T, Tp, operand_dtype, 0, nullptr, st);
+}
+
+hipError_t launch_attention_fill(const void* q, const void* k, const void* vt, const float* key_fill,
+                                 const int* any_pad, void* ctx, int B, int H, int T, int Tp,
+                                 int operand_dtype, hipStream_t st) {
+    return launch_attention_impl(q, k, vt, key_fill, nullptr, ctx, nullptr, B, H, T, Tp, operand_dtype, 1, any_pad, st);
+}
+
+static hipError_t launch_attention_impl(const void* q, const void* k, const void* vt, const float* key_bias,
+                                        const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
+                                        int operand_dtype, int fill_mode, const int* any_pad, hipStream_t st) {
     if (B <= 0 || H <= 0 || T <= 0 || Tp < T || (Tp & 63)) return hipErrorInvalidValue;
     const int nq = (T + 127) / 128;
     dim3 grid(nq * B * H);
@@ -299,7 +325,7 @@ hipError_t launch_attention(const void* q, const void* k, const void* vt, const 
     }();
 #define ESMK_ATTN_LAUNCH(TT, ST, TR)                                                                    \
     hipLaunchKernelGGL((attn_fwd_kernel<TT, ST, TR>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k, \
-                       (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1)
+                       (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad)
 #define ESMK_ATTN_VARIANTS(TT)                                   \
     switch ((var >> 1) & 3) {                                    \
         case 0: ESMK_ATTN_LAUNCH(TT, 2, 0); break;               \

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
                                                          T* __restrict__ y, float* __restrict__ y32,
-                                                         int rows, int E) {
+                                                         int rows, int E, LnExtra ex) {
     constexpr int RPW = (VAR & 1) ? 2 : 1;
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
@@ -180,11 +180,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             const f32x4 g = g4[c], bb = b4[c];
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                const int row = row0 + r;
+                int row = row0 + r;
                 if (row >= rows) continue;
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (v[r][i][e] - mean[r]) * rstd[r] * g[e] + bb[e];
+                if (ex.row_keep != nullptr) {  // msa_transformer.py:171-172: padded positions are zeroed
+                    const float kp = ex.row_keep[row];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] *= kp;
+                }
+                if (ex.map_R > 0) {  // input rows ordered (b,r,c) -> output rows ordered (b,c,r)
+                    const int rc = ex.map_R * ex.map_C;
+                    const int b = row / rc, rem = row - b * rc;
+                    const int rr = rem / ex.map_C, cc = rem - rr * ex.map_C;
+                    row = (b * ex.map_C + cc) * ex.map_R + rr;
+                }
                 if (y) {
                     typename Op<T>::v4 pk;
 #pragma unroll
@@ -209,13 +220,13 @@ constexpr int LN_DEFAULT_VARIANT = 7;
 
 template <typename T, int VAR>
 static hipError_t ln_dispatch_v(const float* x, const float* g, const float* b, void* y, float* y32,
-                                int rows, int E, hipStream_t st) {
+                                int rows, int E, LnExtra ex, hipStream_t st) {
     constexpr int RPW = (VAR & 1) ? 2 : 1;
     const unsigned blocks = (unsigned)((rows + 4 * RPW - 1) / (4 * RPW));
     T* yt = reinterpret_cast<T*>(y);
 #define ESMK_LN(N)                                                                                   \
     hipLaunchKernelGGL((layernorm_kernel<T, N, VAR>), dim3(blocks), dim3(256), 0, st, x, g, b, yt, y32, \
-                       rows, E)
+                       rows, E, ex)
     if (E <= 512) ESMK_LN(2);
     else if (E <= 1280) ESMK_LN(5);
     else if (E <= 2560) ESMK_LN(10);
@@ -227,28 +238,34 @@ static hipError_t ln_dispatch_v(const float* x, const float* g, const float* b, 
 
 template <typename T>
 static hipError_t ln_dispatch(const float* x, const float* g, const float* b, void* y, float* y32,
-                              int rows, int E, int variant, hipStream_t st) {
+                              int rows, int E, int variant, LnExtra ex, hipStream_t st) {
     switch (variant) {
-        case 0: return ln_dispatch_v<T, 0>(x, g, b, y, y32, rows, E, st);
-        case 1: return ln_dispatch_v<T, 1>(x, g, b, y, y32, rows, E, st);
-        case 2: return ln_dispatch_v<T, 2>(x, g, b, y, y32, rows, E, st);
-        case 3: return ln_dispatch_v<T, 3>(x, g, b, y, y32, rows, E, st);
-        case 6: return ln_dispatch_v<T, 6>(x, g, b, y, y32, rows, E, st);
-        case 7: return ln_dispatch_v<T, 7>(x, g, b, y, y32, rows, E, st);
+        case 0: return ln_dispatch_v<T, 0>(x, g, b, y, y32, rows, E, ex, st);
+        case 1: return ln_dispatch_v<T, 1>(x, g, b, y, y32, rows, E, ex, st);
+        case 2: return ln_dispatch_v<T, 2>(x, g, b, y, y32, rows, E, ex, st);
+        case 3: return ln_dispatch_v<T, 3>(x, g, b, y, y32, rows, E, ex, st);
+        case 6: return ln_dispatch_v<T, 6>(x, g, b, y, y32, rows, E, ex, st);
+        case 7: return ln_dispatch_v<T, 7>(x, g, b, y, y32, rows, E, ex, st);
     }
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* y,
                             float* y32, int rows, int E, int operand_dtype, hipStream_t st) {
+    return launch_layernorm_ex(x, gamma, beta, y, y32, rows, E, operand_dtype, LnExtra(), st);
+}
+
+hipError_t launch_layernorm_ex(const float* x, const float* gamma, const float* beta, void* y,
+                               float* y32, int rows, int E, int operand_dtype, LnExtra ex,
+                               hipStream_t st) {
     if (E % 4 != 0 || rows <= 0) return hipErrorInvalidValue;
     // bits 8..11 of operand_dtype: kernel variant + 1 (micro-benchmarks); 0 = engine default
     const int vsel = (operand_dtype >> 8) & 0xf;
     const int variant = vsel ? vsel - 1 : LN_DEFAULT_VARIANT;
     operand_dtype &= 0xff;
     if (operand_dtype == ESMK_DT_BF16)
-        return ln_dispatch<__bf16>(x, gamma, beta, y, y32, rows, E, variant, st);
-    return ln_dispatch<_Float16>(x, gamma, beta, y, y32, rows, E, variant, st);
+        return ln_dispatch<__bf16>(x, gamma, beta, y, y32, rows, E, variant, ex, st);
+    return ln_dispatch<_Float16>(x, gamma, beta, y, y32, rows, E, variant, ex, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -476,6 +493,158 @@ hipError_t launch_contacts(const float* attn, const int64_t* tokens, const float
     const int nt = (S + 31) / 32;
     hipLaunchKernelGGL(contact_out_kernel, dim3(nt, nt, B), dim3(256), 0, st, attn, tokens, w, b,
                        rsum, tsum, out, C, T, eos_idx, bos, eos);
+    return hipGetLastError();
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// MSA Transformer embedding — reference esm/model/msa_transformer.py:152-165 and
+// LearnedPositionalEmbedding.forward (esm/modules.py:240-257).  One workgroup per MSA row (b,r):
+//   x[b,r,c,:] = embed_tokens[tok] + embed_positions[cumsum(nonpad)[c] * nonpad[c] + pad_idx]
+//                + msa_position_embedding[r]                                    (fp32)
+// plus the padding bookkeeping of the axial layers:
+//   keep[b,r,c] = 1 - pad (msa_transformer.py:171-172, axial_attention.py:85-88),
+//   col_fill[(b,c), r] = pad (column attention key mask, axial_attention.py:211-215; (b,c)-major),
+//   any_pad[0] |= pad (the reference drops the mask when the batch has no pad, msa_transformer.py:153-155).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void msa_embed_kernel(const int64_t* __restrict__ tokens,
+                                                         const float* __restrict__ tok_emb,
+                                                         const float* __restrict__ pos_emb,
+                                                         const float* __restrict__ msa_pos,
+                                                         float* __restrict__ x, float* __restrict__ keep,
+                                                         float* __restrict__ col_fill,
+                                                         int* __restrict__ any_pad, int R, int C, int D,
+                                                         int vocab, int pad_idx, int npos) {
+    extern __shared__ int s_pos[];  // [C] position ids, then 4 wave totals
+    const int br = blockIdx.x;      // b * R + r
+    const int b = br / R, r = br - b * R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t* row = tokens + (size_t)br * C;
+    int* s_tot = s_pos + C;
+    // inclusive prefix sum of the non-pad flags over the row, 256 columns per sweep
+    int carry = 0;
+    bool saw_pad = false;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int c = c0 + tid;
+        const int np = (c < C && row[c] != pad_idx) ? 1 : 0;
+        saw_pad |= (c < C && np == 0);
+        int v = np;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(v, o, 64);
+            if (lane >= o) v += t;
+        }
+        if (lane == 63) s_tot[wave] = v;
+        __syncthreads();
+        int base = carry;
+        for (int w = 0; w < wave; ++w) base += s_tot[w];
+        if (c < C) {
+            s_pos[c] = (v + base) * np + pad_idx;
+            keep[(size_t)br * C + c] = (float)np;
+            col_fill[((size_t)b * C + c) * R + r] = np ? 0.f : 1.f;
+        }
+        carry += s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+        __syncthreads();
+    }
+    if (saw_pad) atomicOr(any_pad, 1);
+    const int d4 = D >> 2;
+    const f32x4* mp = msa_pos ? reinterpret_cast<const f32x4*>(msa_pos + (size_t)r * D) : nullptr;
+    for (int idx = tid; idx < C * d4; idx += 256) {
+        const int c = idx / d4, k = idx - c * d4;
+        const int64_t tok = row[c];
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (tok >= 0 && tok < vocab) v = reinterpret_cast<const f32x4*>(tok_emb + (size_t)tok * D)[k];
+        const int ps = min(s_pos[c], npos - 1);
+        const f32x4 pe = reinterpret_cast<const f32x4*>(pos_emb + (size_t)ps * D)[k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += pe[e];
+        if (mp) {
+            const f32x4 m4 = mp[k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += m4[e];
+        }
+        reinterpret_cast<f32x4*>(x + ((size_t)br * C + c) * D)[k] = v;
+    }
+}
+
+hipError_t launch_msa_embed(const int64_t* tokens, const float* tok_emb, const float* pos_emb,
+                            const float* msa_pos, float* x, float* keep, float* col_fill, int* any_pad,
+                            int B, int R, int C, int D, int vocab, int pad_idx, int npos, hipStream_t st) {
+    if (D % 4 != 0) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(any_pad, 0, sizeof(int), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(msa_embed_kernel, dim3(B * R), dim3(256), (size_t)(C + 4) * sizeof(int), st, tokens,
+                       tok_emb, pos_emb, msa_pos, x, keep, col_fill, any_pad, R, C, D, vocab, pad_idx, npos);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-attention softmax — reference esm/axial_attention.py:96-100 (columns that are padded in row 0
+// are filled with -10000) and :127 (softmax over the key column j).  One wave per (b,h,i) row.
+//   scores fp32 [B*H, C, ldp]  ->  probs (operand dtype) [B*H, C, ldp], columns >= C zeroed (they are the
+//   K padding of the context GEMM), and optionally fp32 row_attentions[b, layer, h, i, :] (msa_transformer.py:195-196)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void msa_row_softmax_kernel(const float* __restrict__ scores,
+                                                               const float* __restrict__ keep,
+                                                               const int* __restrict__ any_pad,
+                                                               T* __restrict__ probs,
+                                                               float* __restrict__ attn_out, int B, int H,
+                                                               int R, int C, int ldp, int layer, int Ltot) {
+    const int lane = threadIdx.x & 63;
+    const int rowid = blockIdx.x * 4 + (threadIdx.x >> 6);  // (b*H + h)*C + i
+    const int total = B * H * C;
+    if (rowid >= total) return;
+    const int bh = rowid / C, i = rowid - bh * C;
+    const int b = bh / H, h = bh - b * H;
+    const bool masked = any_pad[0] != 0;
+    const float* srow = scores + (size_t)rowid * ldp;
+    const float* k0 = keep + (size_t)b * R * C;  // row 0 of MSA b: keep[b,0,j]
+    constexpr int MAXJ = 16;                       // columns per lane: C <= 1024
+    float v[MAXJ];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < MAXJ; ++q) {
+        const int j = lane + 64 * q;
+        float s = -INFINITY;
+        if (j < C) {
+            s = srow[j];
+            if (masked && k0[j] == 0.f) s = -10000.f;
+        }
+        v[q] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXJ; ++q) {
+        v[q] = (lane + 64 * q < C) ? expf(v[q] - mx) : 0.f;
+        sum += v[q];
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    T* prow = probs + (size_t)rowid * ldp;
+    float* arow = attn_out ? attn_out + ((((size_t)b * Ltot + layer) * H + h) * C + i) * C : nullptr;
+#pragma unroll
+    for (int q = 0; q < MAXJ; ++q) {
+        const int j = lane + 64 * q;
+        if (j < ldp) prow[j] = Op<T>::from(v[q] * inv);
+        if (arow && j < C) arow[j] = v[q] * inv;
+    }
+}
+
+hipError_t launch_msa_row_softmax(const float* scores, const float* keep, const int* any_pad, void* probs,
+                                  float* attn_out, int B, int H, int R, int C, int ldp, int layer,
+                                  int num_layers_total, int operand_dtype, hipStream_t st) {
+    if (C > 1024 || ldp > 1024 || ldp < C) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((B * H * C + 3) / 4));
+    if (operand_dtype == ESMK_DT_BF16)
+        hipLaunchKernelGGL((msa_row_softmax_kernel<__bf16>), grid, dim3(256), 0, st, scores, keep, any_pad,
+                           (__bf16*)probs, attn_out, B, H, R, C, ldp, layer, num_layers_total);
+    else
+        hipLaunchKernelGGL((msa_row_softmax_kernel<_Float16>), grid, dim3(256), 0, st, scores, keep, any_pad,
+                           (_Float16*)probs, attn_out, B, H, R, C, ldp, layer, num_layers_total);
     return hipGetLastError();
 }
 

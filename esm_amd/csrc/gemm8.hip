@@ -70,6 +70,18 @@ constexpr int epilogue_stores() {
     return (EPI == EPI_STORE_F32 || EPI == EPI_GELU_F32 || EPI == EPI_RESID_F32) ? 32 : 16;
 }
 
+// EPI_RESID_F32 row remap of the MSA column-attention block: the GEMM runs on rows ordered (b,c,r)
+// (column attention treats every MSA column as a sequence), the residual stream is ordered (b,r,c).
+template <bool GEN>
+ESMK_DEV int remap_row(const GemmArgs& p, int m) {
+    if constexpr (!GEN) return m;
+    if (p.rowmap_R == 0) return m;
+    const int rc = p.rowmap_R * p.rowmap_C;
+    const int b = m / rc, rem = m - b * rc;
+    const int c = rem / p.rowmap_R, r = rem - c * p.rowmap_R;
+    return (b * p.rowmap_R + r) * p.rowmap_C + c;
+}
+
 template <typename T>
 ESMK_DEV typename Op<T>::v4 pack4_(float a, float b, float c, float d) {
     typename Op<T>::v4 v;
@@ -92,9 +104,9 @@ ESMK_DEV typename Op<T>::v4 pack4_(float a, float b, float c, float d) {
 // EPI_V_T, whose bias varies with the lane instead of the register.  FULL = the wave's block lies
 // completely inside [0,M) x [0,N): no store is predicated, so the wave issues exactly
 // epilogue_stores<EPI>() store instructions.
-template <typename T, int EPI, bool FULL, bool NOSTORE = false>
+template <typename T, int EPI, bool FULL, bool NOSTORE = false, bool GEN = false>
 ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int n_base, int lane,
-                        char* wl) {
+                        char* wl, size_t out_off, int zo, int zi) {
     using V4 = typename Op<T>::v4;
     using V8 = typename Op<T>::v8;
     const int h = lane >> 5, lm = lane & 31;
@@ -107,6 +119,13 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
         T* vt = reinterpret_cast<T*>(p.vt);
         const float bv0 = p.bias[n_base + lm], bv1 = p.bias[n_base + 32 + lm];
         const bool aligned = FULL || (p.T % 32 == 0);  // a 32-token piece = one aligned run of one sequence
+        const bool perm = !GEN || (p.vt_rows == 0);  // ESM-2 attention consumes permuted keys, the MSA context GEMM plain ones
+        // row index of vt for sequence `sq`: ESM-2 [B,H,64,Tp]; MSA row attention [B,H,R,64,Tp], sq = (b,r)
+        auto vt_row0 = [&](int sq) -> size_t {
+            if (!GEN || p.vt_rows == 0) return (size_t)(sq * p.H + head) * 64;
+            const int bm = sq / p.vt_rows, r = sq - bm * p.vt_rows;
+            return ((size_t)(bm * p.H + head) * p.vt_rows + r) * 64;
+        };
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             // LDS piece: 64 rows (dv) x 64 B (32 tokens); 16-byte chunk c holds 8 token slots
@@ -117,8 +136,8 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     // tokens 8g + 4h + e (e = 0..3) of the piece
-                    const int chunk = aligned ? 2 * (g >> 1) + h : g;
-                    const int half = aligned ? (g & 1) : h;
+                    const int chunk = (aligned && perm) ? 2 * (g >> 1) + h : g;
+                    const int half = (aligned && perm) ? (g & 1) : h;
                     *reinterpret_cast<V4*>(wl + dv * 64 + ((chunk ^ ((dv >> 1) & 3)) << 4) + 8 * half) =
                         pack4_<T>(acc[j][i][4 * g] + bv, acc[j][i][4 * g + 1] + bv,
                                   acc[j][i][4 * g + 2] + bv, acc[j][i][4 * g + 3] + bv);
@@ -128,7 +147,7 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
             if (aligned) {
                 if (FULL || mp < p.M) {
                     const int b = mp / p.T, t0 = mp - b * p.T;
-                    T* base = vt + ((size_t)(b * p.H + head) * 64) * p.Tp + t0;
+                    T* base = vt + vt_row0(b) * p.Tp + t0;
                     V8 v[4];
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
@@ -154,8 +173,8 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
                                                             2 * (tl & 7));
                     const int b = m / p.T, t = m - b * p.T;
                     const int t16 = t & 15;
-                    const int tp = (t & ~15) | ((((t16 >> 2) & 1) << 3) | (((t16 >> 3) & 1) << 2) | (t16 & 3));
-                    vt[((size_t)(b * p.H + head) * 64 + r) * (size_t)p.Tp + tp] = v;
+                    const int tp = perm ? ((t & ~15) | ((((t16 >> 2) & 1) << 3) | (((t16 >> 3) & 1) << 2) | (t16 & 3))) : t;
+                    vt[(vt_row0(b) + r) * (size_t)p.Tp + tp] = v;
                 }
             }
         }
@@ -169,6 +188,8 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
         for (int i = 0; i < 4; ++i) {
             const int m = min(m_base + 32 * i + lm, p.M - 1);
             const int t = m % p.T;
+            // MSA row attention zeroes q at padded positions (axial_attention.py:85-88)
+            const float keep = (GEN && which == 0 && p.row_keep != nullptr) ? p.row_keep[m] : 1.0f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = 8 * g + 4 * h;  // first of 4 consecutive dims in [0,32)
@@ -178,8 +199,8 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // bias, q scaling (mha.py:261), x*cos + rotate_half(x)*sin (rotary_embedding.py:11-20)
-                    const float a1 = acc[0][i][4 * g + e] * sc;
-                    const float a2 = acc[1][i][4 * g + e] * sc;
+                    const float a1 = acc[0][i][4 * g + e] * (sc * keep);
+                    const float a2 = acc[1][i][4 * g + e] * (sc * keep);
                     y1[e] = a1 * c[e] - a2 * s[e];
                     y2[e] = a2 * c[e] + a1 * s[e];
                 }
@@ -206,8 +227,9 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
                 }
             }
         }
-    } else if constexpr (EPI == EPI_STORE_T || EPI == EPI_GELU_T) {
-        T* out = reinterpret_cast<T*>(p.out);
+    } else if constexpr (EPI == EPI_STORE_T || EPI == EPI_GELU_T || EPI == EPI_MSA_CTX) {
+        T* out = reinterpret_cast<T*>(reinterpret_cast<char*>(p.out) + out_off);
+        const int ldc = (GEN && p.ldc > 0) ? p.ldc : p.N;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -235,22 +257,32 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
                 const int pc = it * 64 + lane;
                 const int r = pc >> 3, cc = pc & 7;
                 const int m = m_base + 32 * i + r, n = n_base + cc * 8;
-                if constexpr (NOSTORE) asm volatile("" ::"v"(v[it]));
-                else if (FULL || (m < p.M && n < p.N)) *reinterpret_cast<V8*>(out + (size_t)m * p.N + n) = v[it];
+                if constexpr (NOSTORE) {
+                    asm volatile("" ::"v"(v[it]));
+                } else if constexpr (EPI == EPI_MSA_CTX) {
+                    // rows m = query column i, the wave's 64 columns = one MSA row r = n_base / 64:
+                    // ctx[((zo*R + r)*C + m)*ldc + zi*64 + (n - n_base)]   (axial_attention.py:111-112)
+                    if (FULL || (m < p.M && n < p.N))
+                        *reinterpret_cast<V8*>(out + ((size_t)(zo * p.ctx_R + (n_base >> 6)) * p.ctx_C + m) * ldc +
+                                               zi * 64 + cc * 8) = v[it];
+                } else if (FULL || (m < p.M && n < p.N)) {
+                    *reinterpret_cast<V8*>(out + (size_t)m * ldc + n) = v[it];
+                }
             }
         }
     } else {
         // fp32 outputs: 8 pieces of 32 rows x 32 columns (128-byte row segments)
-        float* out = reinterpret_cast<float*>(p.out);
+        float* out = reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + out_off);
+        const int ldc = (GEN && p.ldc > 0) ? p.ldc : p.N;
         f32x4 old[4], nxt[4];
         auto load_old = [&](f32x4 (&dst)[4], int piece) {
             const int i = piece >> 1, j = piece & 1;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int pc = it * 64 + lane;
-                const int m = min(m_base + 32 * i + (pc >> 3), p.M - 1);
+                const int m = remap_row<GEN>(p, min(m_base + 32 * i + (pc >> 3), p.M - 1));
                 const int n = min(n_base + 32 * j + (pc & 7) * 4, p.N - 4);
-                dst[it] = *reinterpret_cast<const f32x4*>(out + (size_t)m * p.N + n);
+                dst[it] = *reinterpret_cast<const f32x4*>(out + (size_t)m * ldc + n);
             }
         };
         if constexpr (EPI == EPI_RESID_F32) load_old(old, 0);
@@ -284,7 +316,8 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
                 if constexpr (EPI == EPI_RESID_F32)
                     v = f32x4{old[it][0] + v[0], old[it][1] + v[1], old[it][2] + v[2], old[it][3] + v[3]};
                 const int m = m_base + 32 * i + r, n = n_base + 32 * j + cc * 4;
-                if (FULL || (m < p.M && n < p.N)) *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = v;
+                if (FULL || (m < p.M && n < p.N))
+                    *reinterpret_cast<f32x4*>(out + (size_t)(EPI == EPI_RESID_F32 ? remap_row<GEN>(p, m) : m) * ldc + n) = v;
             }
             if constexpr (EPI == EPI_RESID_F32) {
 #pragma unroll
@@ -307,7 +340,9 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
 // PF > 0: every wave touches one dword of 64 of the 512 cache lines of stream position s + PF per K
 // tile (an L2 prefetch: the LDS-DMA of that position then hits the XCD's L2 instead of paying the
 // fabric / HBM latency inside the two-K-tile-deep DMA window).
-template <typename T, int EPI, int SCHED = 0, int DBG = 0, int PF = 0>
+// GEN: generalised addressing (strides, batch, row remaps; GemmArgs fields after `scaling`) — a separate
+// instantiation so that the dense layer-stack kernels keep their register budget.
+template <typename T, int EPI, int SCHED = 0, int DBG = 0, int PF = 0, bool GEN = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long long* timing) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V8 = typename Op<T>::v8;
@@ -317,11 +352,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
     const int grp = wave >> 2;  // M half of the tile AND ping-pong group
     const int wn = wave & 3;    // 64-column slice of the tile
     const int nk = p.K >> 6;
-    const unsigned row_bytes = (unsigned)p.K * 2u;
+    const unsigned a_rb = (GEN && p.a_row_bytes) ? (unsigned)p.a_row_bytes : (unsigned)p.K * 2u;  // operand row strides
+    const unsigned w_rb = (GEN && p.w_row_bytes) ? (unsigned)p.w_row_bytes : (unsigned)p.K * 2u;
+    const long long a_kt = (GEN && p.a_kt_bytes) ? p.a_kt_bytes : 128, w_kt = (GEN && p.w_kt_bytes) ? p.w_kt_bytes : 128;
+    const int n_valid = (GEN && p.n_valid > 0) ? p.n_valid : p.N;
+    const int nbatch = GEN ? p.batch : 1, binner = GEN ? p.batch_inner : 1;
 
     // ---- static persistent schedule -----------------------------------------------------------
     const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
-    const int total = tiles_m * tiles_n;
+    const int tiles_mn = tiles_m * tiles_n;
+    const int total = tiles_mn * nbatch;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     const int q8 = total >> 3, r8 = total & 7;
     const int start = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
@@ -330,8 +370,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
     if (n_my == 0) return;
     const int panel_c = p.panel_c > 0 ? p.panel_c : tiles_n;
     const int panel_full = tiles_m * panel_c;
-    auto tile_coords = [&](int it, int& tmi, int& tni) {
-        const int o = start + slot + it * nslot;
+    auto tile_coords = [&](int it, int& tmi, int& tni, int& bz) {
+        const int og = start + slot + it * nslot;
+        bz = __builtin_amdgcn_readfirstlane(nbatch > 1 ? og / tiles_mn : 0);
+        const int o = og - bz * tiles_mn;
         const int pnl = o / panel_full;
         const int rem = o - pnl * panel_full;
         const int w = min(panel_c, tiles_n - pnl * panel_c);
@@ -351,22 +393,25 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
         unsigned off0, off1; // per-lane byte offsets of the two DMA instructions
     };
     auto set_tile = [&](Stream& s, int unit, int it) {
-        int tmi, tni;
-        tile_coords(it, tmi, tni);
+        int tmi, tni, bz;
+        tile_coords(it, tmi, tni, bz);
+        const int zo = bz / binner, zi = bz - zo * binner;
+        const long long a_boff = GEN ? zo * p.a_bo + zi * p.a_bi : 0, w_boff = GEN ? zo * p.w_bo + zi * p.w_bi : 0;
         s.it = it;
         s.kt = 0;
         if (unit == 0 || unit == 3) {  // A rows: group (ur>>6) * 128 + (unit 3 ? 64 : 0) + (ur & 63)
             const int lim = p.M - tmi * 256 - 1;
             const int add = unit == 3 ? 64 : 0;
-            s.base = reinterpret_cast<const char*>(p.A) + (size_t)tmi * 256 * row_bytes;
-            s.off0 = (unsigned)min((ur0 >> 6) * 128 + add + (ur0 & 63), lim) * row_bytes + cs0;
-            s.off1 = (unsigned)min((ur1 >> 6) * 128 + add + (ur1 & 63), lim) * row_bytes + cs1;
+            s.base = reinterpret_cast<const char*>(p.A) + (size_t)tmi * 256 * a_rb + a_boff;
+            s.off0 = (unsigned)min((ur0 >> 6) * 128 + add + (ur0 & 63), lim) * a_rb + cs0;
+            s.off1 = (unsigned)min((ur1 >> 6) * 128 + add + (ur1 & 63), lim) * a_rb + cs1;
         } else {  // W rows: wave column (ur>>5) * 64 + (unit 2 ? 32 : 0) + (ur & 31)
-            const int lim = p.N - tni * 256 - 1;
+            const int lim = n_valid - tni * 256 - 1;
             const int add = unit == 2 ? 32 : 0;
-            s.base = reinterpret_cast<const char*>(p.W) + (size_t)tni * 256 * row_bytes;
-            s.off0 = (unsigned)min((ur0 >> 5) * 64 + add + (ur0 & 31), lim) * row_bytes + cs0;
-            s.off1 = (unsigned)min((ur1 >> 5) * 64 + add + (ur1 & 31), lim) * row_bytes + cs1;
+            s.base = reinterpret_cast<const char*>(p.W) + (size_t)tni * 256 * w_rb + w_boff;
+            s.off0 = (unsigned)max(min((ur0 >> 5) * 64 + add + (ur0 & 31), lim), 0) * w_rb + cs0;
+            s.off1 = (unsigned)max(min((ur1 >> 5) * 64 + add + (ur1 & 31), lim), 0) * w_rb + cs1;
+            if (lim < 0) s.base -= (size_t)tni * 256 * w_rb - (size_t)max(n_valid - 1, 0) * w_rb;  // whole tile past n_valid
         }
     };
     auto issue = [&](Stream& s, int unit, int buf) {
@@ -379,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
         // K tile is re-issued (into a dead buffer) so the vmcnt bookkeeping stays uniform
         if (s.kt + 1 < nk) {
             s.kt = __builtin_amdgcn_readfirstlane(s.kt + 1);
-            if constexpr (!(DBG & 64)) s.base += 128;
+            if constexpr (!(DBG & 64)) s.base += (unit == 0 || unit == 3) ? a_kt : w_kt;
         } else if (s.it + 1 < n_my) {
             set_tile(s, unit, s.it + 1);
         }
@@ -401,17 +446,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
     Stream sP;
     unsigned pf_dummy = 0;  // destination of the prefetch loads; never read
     auto set_tile_pf = [&](int it) {
-        int tmi, tni;
-        tile_coords(it, tmi, tni);
+        int tmi, tni, bz;
+        tile_coords(it, tmi, tni, bz);
         sP.it = it;
         sP.kt = 0;
         const int row = (wave & 3) * 64 + lane;
         if (wave < 4) {
-            sP.base = reinterpret_cast<const char*>(p.A) + (size_t)tmi * 256 * row_bytes;
-            sP.off0 = (unsigned)min(row, p.M - tmi * 256 - 1) * row_bytes;
+            sP.base = reinterpret_cast<const char*>(p.A) + (size_t)tmi * 256 * a_rb;
+            sP.off0 = (unsigned)min(row, p.M - tmi * 256 - 1) * a_rb;
         } else {
-            sP.base = reinterpret_cast<const char*>(p.W) + (size_t)tni * 256 * row_bytes;
-            sP.off0 = (unsigned)min(row, p.N - tni * 256 - 1) * row_bytes;
+            sP.base = reinterpret_cast<const char*>(p.W) + (size_t)tni * 256 * w_rb;
+            sP.off0 = (unsigned)min(row, p.N - tni * 256 - 1) * w_rb;
         }
     };
     auto advance_pf = [&]() {
@@ -562,7 +607,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
                 const int L = q * 64 + lane;
                 const int row = min(m_base_cur + (L >> 1), p.M - 1);
                 const int n = min(n_base_cur + (L & 1) * 32, p.N - 4);
-                const float* addr = xo_ + (size_t)row * p.N + n;
+                const float* addr = xo_ + (size_t)remap_row<GEN>(p, row) * ((GEN && p.ldc > 0) ? p.ldc : p.N) + n;
                 asm volatile("global_load_dword %0, %1, off" : "+v"(x_dummy) : "v"(addr) : "memory");
             }
         }
@@ -650,8 +695,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
     };
 
     for (int it = 0; it < n_my; ++it) {
-        int tmi, tni;
-        tile_coords(it, tmi, tni);
+        int tmi, tni, bz;
+        tile_coords(it, tmi, tni, bz);
+        const int zo = bz / binner, zi = bz - zo * binner;
+        const size_t out_off = GEN ? (size_t)(zo * p.o_bo + zi * p.o_bi) : 0;
         const int m_base = tmi * 256 + grp * 128, n_base = tni * 256 + wn * 64;
         init_acc(n_base);
         stamp(it, 0);
@@ -677,8 +724,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
         } else {
             bool full = (m_base + 128 <= p.M) && (n_base + 64 <= p.N);
             if constexpr (EPI == EPI_V_T) full = full && (p.T % 32 == 0);
-            if (full) epilogue8<T, EPI, true, (DBG & 16) != 0>(p, acc, m_base, n_base, lane, slice);
-            else epilogue8<T, EPI, false, (DBG & 16) != 0>(p, acc, m_base, n_base, lane, slice);
+            if (full) epilogue8<T, EPI, true, (DBG & 16) != 0, GEN>(p, acc, m_base, n_base, lane, slice, out_off, zo, zi);
+            else epilogue8<T, EPI, false, (DBG & 16) != 0, GEN>(p, acc, m_base, n_base, lane, slice, out_off, zo, zi);
             young_stores = full && !(DBG & 16);
         }
         if constexpr (XPF) asm volatile("" : "+v"(x_dummy));  // the epilogue's own loads retired them
@@ -708,10 +755,10 @@ void gemm8_set_timing(unsigned long long* dev_buf) { g_timing = dev_buf; }
 
 constexpr int PF_DEFAULT = 0;
 
-template <typename T, int EPI, int SCHED = 0, int DBG = 0, int PF = PF_DEFAULT>
+template <typename T, int EPI, int SCHED = 0, int DBG = 0, int PF = PF_DEFAULT, bool GEN = false>
 static hipError_t launch8(GemmArgs p, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = gemm8_kernel<T, EPI, SCHED, DBG, PF>;
+    auto kern = gemm8_kernel<T, EPI, SCHED, DBG, PF, GEN>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
@@ -760,18 +807,9 @@ static hipError_t dispatch8(const GemmArgs& p, int epi, hipStream_t st) {
                     case 0x40: return launch8<T, EPI_STORE_T, 0, 32>(p, st);
                     case 0x60: return launch8<T, EPI_STORE_T, 0, 64>(p, st);
                     case 0x68: return launch8<T, EPI_STORE_T, 0, 64 + 8>(p, st);
-                    case 0x82: return launch8<T, EPI_STORE_T, 0, 0, 2>(p, st);
-                    case 0x83: return launch8<T, EPI_STORE_T, 0, 0, 3>(p, st);
-                    case 0x84: return launch8<T, EPI_STORE_T, 0, 0, 4>(p, st);
-                    case 0x86: return launch8<T, EPI_STORE_T, 0, 0, 6>(p, st);
-                    case 0x8c: return launch8<T, EPI_STORE_T, 0, 8, 4>(p, st);
                 }
             }
             if (p.dbg == 0x90 && epi == EPI_RESID_F32) return launch8<T, EPI_RESID_F32, 0, 128>(p, st);
-            if (p.dbg == 0x84) {
-                if (epi == EPI_GELU_T) return launch8<T, EPI_GELU_T, 0, 0, 4>(p, st);
-                if (epi == EPI_RESID_F32) return launch8<T, EPI_RESID_F32, 0, 0, 4>(p, st);
-            }
         }
         return hipErrorInvalidValue;
     }
@@ -786,18 +824,32 @@ static hipError_t dispatch8(const GemmArgs& p, int epi, hipStream_t st) {
         return 0;
     }();
     if (mode == 1) return v1ref_launch(p, epi, std::is_same<T, _Float16>::value ? ESMK_DT_F16 : ESMK_DT_BF16, st);
-#define ESMK_CASES(SC, DB, PFD)                                                   \
-    switch (epi) {                                                                \
-        case EPI_STORE_T: return launch8<T, EPI_STORE_T, SC, DB, PFD>(p, st);     \
-        case EPI_STORE_F32: return launch8<T, EPI_STORE_F32, SC, DB, PFD>(p, st); \
-        case EPI_GELU_T: return launch8<T, EPI_GELU_T, SC, DB, PFD>(p, st);       \
-        case EPI_GELU_F32: return launch8<T, EPI_GELU_F32, SC, DB, PFD>(p, st);   \
-        case EPI_RESID_F32: return launch8<T, EPI_RESID_F32, SC, DB, PFD>(p, st); \
-        case EPI_QKV_ROPE: return launch8<T, EPI_QKV_ROPE, SC, DB, PFD>(p, st);   \
-        case EPI_V_T: return launch8<T, EPI_V_T, SC, DB, PFD>(p, st);             \
+    // generalised addressing requested?  (MSA Transformer calls, batched / strided / remapped GEMMs)
+    const bool gen = p.a_row_bytes || p.w_row_bytes || p.a_kt_bytes || p.w_kt_bytes || p.batch > 1 || p.n_valid > 0 ||
+                     p.ldc > 0 || p.row_keep != nullptr || p.vt_rows > 0 || p.rowmap_R > 0 || epi == EPI_MSA_CTX;
+#define ESMK_CASES(SC, DB, PFD)                                                          \
+    switch (epi) {                                                                       \
+        case EPI_STORE_T: return launch8<T, EPI_STORE_T, SC, DB, PFD>(p, st);            \
+        case EPI_STORE_F32: return launch8<T, EPI_STORE_F32, SC, DB, PFD>(p, st);        \
+        case EPI_GELU_T: return launch8<T, EPI_GELU_T, SC, DB, PFD>(p, st);              \
+        case EPI_GELU_F32: return launch8<T, EPI_GELU_F32, SC, DB, PFD>(p, st);          \
+        case EPI_RESID_F32: return launch8<T, EPI_RESID_F32, SC, DB, PFD>(p, st);        \
+        case EPI_QKV_ROPE: return launch8<T, EPI_QKV_ROPE, SC, DB, PFD>(p, st);          \
+        case EPI_V_T: return launch8<T, EPI_V_T, SC, DB, PFD>(p, st);                    \
+    }
+    if (gen) {
+        switch (epi) {
+            case EPI_STORE_T: return launch8<T, EPI_STORE_T, 0, 0, 0, true>(p, st);
+            case EPI_STORE_F32: return launch8<T, EPI_STORE_F32, 0, 0, 0, true>(p, st);
+            case EPI_GELU_T: return launch8<T, EPI_GELU_T, 0, 0, 0, true>(p, st);
+            case EPI_RESID_F32: return launch8<T, EPI_RESID_F32, 0, 0, 0, true>(p, st);
+            case EPI_QKV_ROPE: return launch8<T, EPI_QKV_ROPE, 0, 0, 0, true>(p, st);
+            case EPI_V_T: return launch8<T, EPI_V_T, 0, 0, 0, true>(p, st);
+            case EPI_MSA_CTX: return launch8<T, EPI_MSA_CTX, 0, 0, 0, true>(p, st);
+        }
+        return hipErrorInvalidValue;
     }
     if constexpr (std::is_same<T, _Float16>::value) {
-        if (mode == 2) { ESMK_CASES(0, 0, 4) }
         if (mode == 3) { ESMK_CASES(0, 32, 0) }
         if (mode == 4) { ESMK_CASES(0, 128, 0) }
     }
@@ -808,7 +860,7 @@ static hipError_t dispatch8(const GemmArgs& p, int epi, hipStream_t st) {
 
 bool gemm8_supports(const GemmArgs& p, int epi) {
     if (p.K % 64 != 0 || p.N % 8 != 0 || p.M <= 0) return false;
-    if ((epi == EPI_QKV_ROPE || epi == EPI_V_T) && p.N % 64 != 0) return false;
+    if ((epi == EPI_QKV_ROPE || epi == EPI_V_T || epi == EPI_MSA_CTX) && p.N % 64 != 0) return false;
     return true;
 }
 

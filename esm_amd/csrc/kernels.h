@@ -14,7 +14,8 @@ enum {
     EPI_GELU_F32 = 3,   // out fp32               = gelu(acc + bias)
     EPI_RESID_F32 = 4,  // out fp32              += acc + bias
     EPI_QKV_ROPE = 5,   // fused q,k projection: bias, q scale, RoPE, head-major store (head_dim 64)
-    EPI_V_T = 6         // v projection stored transposed [B,H,64,Tp] for the attention kernel
+    EPI_V_T = 6,        // v projection stored transposed [B,H,64,Tp] for the attention kernel
+    EPI_MSA_CTX = 7     // MSA row attention context: out[((zo*R + n/64)*C + m)*ldc + zi*64 + n%64] (operand dtype)
 };
 
 struct GemmArgs {
@@ -35,6 +36,17 @@ struct GemmArgs {
     const float* sin = nullptr;  // [T,32]
     int T = 0, H = 0, E = 0, Tp = 0;
     float scaling = 1.f;
+    // ---- generalised addressing of the persistent kernel (gemm8.hip); 0 = dense default ------------
+    long long a_row_bytes = 0, w_row_bytes = 0;  // stride between consecutive operand rows (2K)
+    long long a_kt_bytes = 0, w_kt_bytes = 0;    // stride between consecutive 64-wide K tiles (128)
+    int batch = 1, batch_inner = 1;              // batched GEMM: z = zo * batch_inner + zi
+    long long a_bo = 0, a_bi = 0, w_bo = 0, w_bi = 0, o_bo = 0, o_bi = 0;  // byte offsets per zo / zi
+    int n_valid = 0;                  // W rows that exist (default N): loads of rows >= n_valid are clamped
+    int ldc = 0;                      // output row stride in elements (default N)
+    const float* row_keep = nullptr;  // EPI_QKV_ROPE: q row m is multiplied by row_keep[m] (axial_attention.py:85-88)
+    int vt_rows = 0;                  // EPI_V_T: > 0 selects the layout [B,H,R = vt_rows,64,Tp], keys not permuted
+    int rowmap_R = 0, rowmap_C = 0;   // EPI_RESID_F32: GEMM row (b,c,r) is added to output row (b,r,c)
+    int ctx_R = 0, ctx_C = 0;         // EPI_MSA_CTX geometry
 };
 
 hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st);
@@ -58,6 +70,23 @@ hipError_t launch_embed(const int64_t* tokens, const float* table, const float* 
 // LayerNorm(E, eps=1e-5) (modules.py:68-81): fp32 rows -> operand-dtype and/or fp32 rows
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* y,
                             float* y32, int rows, int E, int operand_dtype, hipStream_t st);
+// MSA Transformer variants of the same kernel: output rows scaled by row_keep[row] (padded positions
+// zeroed, msa_transformer.py:171-172) and/or written in (b,c,r) row order for the column-attention block
+struct LnExtra {
+    const float* row_keep = nullptr;
+    int map_R = 0, map_C = 0;
+};
+hipError_t launch_layernorm_ex(const float* x, const float* gamma, const float* beta, void* y,
+                               float* y32, int rows, int E, int operand_dtype, LnExtra ex,
+                               hipStream_t st);
+// MSA embedding (msa_transformer.py:152-165, modules.py:240-257) and padding bookkeeping
+hipError_t launch_msa_embed(const int64_t* tokens, const float* tok_emb, const float* pos_emb,
+                            const float* msa_pos, float* x, float* keep, float* col_fill, int* any_pad,
+                            int B, int R, int C, int D, int vocab, int pad_idx, int npos, hipStream_t st);
+// tied row attention softmax (axial_attention.py:96-100,127)
+hipError_t launch_msa_row_softmax(const float* scores, const float* keep, const int* any_pad, void* probs,
+                                  float* attn_out, int B, int H, int R, int C, int ldp, int layer,
+                                  int num_layers_total, int operand_dtype, hipStream_t st);
 // dtype conversion of a parameter tensor into the packed image
 hipError_t launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype, size_t n,
                           hipStream_t st);
@@ -74,6 +103,11 @@ hipError_t launch_contacts(const float* attn, const int64_t* tokens, const float
 hipError_t launch_attention(const void* q, const void* k, const void* vt, const float* key_bias,
                             const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
                             int operand_dtype, hipStream_t st);
+// same kernel, MSA column attention: key_fill[b,t] != 0 REPLACES the score by -10000 (masked_fill,
+// axial_attention.py:211-215) and is only applied when any_pad[0] != 0
+hipError_t launch_attention_fill(const void* q, const void* k, const void* vt, const float* key_fill,
+                                 const int* any_pad, void* ctx, int B, int H, int T, int Tp,
+                                 int operand_dtype, hipStream_t st);
 hipError_t launch_attention_probs(const void* q, const void* k, const float* lse,
                                   const float* key_bias, float* probs, int B, int H, int T,
                                   int layer, int num_layers_total, int operand_dtype,

@@ -95,6 +95,39 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
                  void* contacts_out_dev, void* workspace_dev, size_t workspace_bytes,
                  void* stream);
 
+/* ---- MSA Transformer (reference esm/model/msa_transformer.py:20-238, esm/axial_attention.py) -------- */
+
+/* Constructor arguments of MSATransformer (msa_transformer.py:88-144) + alphabet ids. */
+typedef struct esmk_msa_config {
+    int32_t num_layers, embed_dim, num_heads, ffn_dim, vocab;
+    int32_t pad_idx, mask_idx, cls_idx, eos_idx, prepend_bos, append_eos;
+    int32_t num_positions;               /* rows of embed_positions.weight = max_positions + pad_idx + 1 */
+    int32_t has_msa_position_embedding;  /* args.embed_positions_msa (msa_transformer.py:104-112) */
+    int32_t operand_dtype;               /* ESMK_F16 or ESMK_BF16 */
+} esmk_msa_config;
+
+/* Replaces MSATransformer.__init__; the handle is packed with esmk_pack_weight (MSATransformer
+ * state-dict keys: layers.N.{row,column}_self_attention.layer.*_proj.*, ...layer_norm.*,
+ * layers.N.feed_forward_layer.layer.fc{1,2}.*, embed_positions.weight, msa_position_embedding, ...)
+ * and freed with esmk_destroy. */
+int esmk_msa_create(const esmk_msa_config* cfg, esmk_model** out);
+int esmk_msa_workspace_bytes(const esmk_model* m, int B, int R, int C, uint32_t out_flags, size_t* bytes);
+
+/* Replaces MSATransformer.forward (msa_transformer.py:146-220): embedding (+ LearnedPositionalEmbedding
+ * modules.py:240-257), AxialTransformerLayer stack (modules.py:196-221: RowSelfAttention
+ * axial_attention.py:75-130, ColumnSelfAttention :185-239, FeedForwardNetwork modules.py:395-418),
+ * final LayerNorm, RobertaLMHead, ContactPredictionHead on the row attentions.
+ *   tokens_dev       int64 [B,R,C]
+ *   repr_out_dev[i]  fp32 [B,R,C,E]
+ *   logits_out_dev   fp32 [B,R,C,V]        (iff ESMK_OUT_LOGITS)
+ *   row_attn_out_dev fp32 [B,L,H,C,C]      (iff ESMK_OUT_ATTN or ESMK_OUT_CONTACTS)
+ *   contacts_out_dev fp32 [B,C-1,C-1]      (iff ESMK_OUT_CONTACTS)
+ * col_attentions [B,L,H,C,R,R] are not produced by this entry point. */
+int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_dev, int B, int R, int C,
+                     const int32_t* repr_layers, int n_repr, void* const* repr_out_dev, uint32_t out_flags,
+                     void* logits_out_dev, void* row_attn_out_dev, void* contacts_out_dev,
+                     void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* Per-kernel-class timing of esmk_forward with HIP events recorded on the launch stream
  * (measurement support for bench.py; the reference has no counterpart).
  * esmk_profile_begin() arms it; every launch of the following esmk_forward() calls is bracketed
