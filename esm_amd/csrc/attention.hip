@@ -307,9 +307,9 @@ hipError_t launch_attention(const void* q, const void* k, const void* vt, const 
 }
 
 hipError_t launch_attention_fill(const void* q, const void* k, const void* vt, const float* key_fill,
-                                 const int* any_pad, void* ctx, int B, int H, int T, int Tp,
+                                 const int* any_pad, void* ctx, float* lse, int B, int H, int T, int Tp,
                                  int operand_dtype, hipStream_t st) {
-    return launch_attention_impl(q, k, vt, key_fill, nullptr, ctx, nullptr, B, H, T, Tp, operand_dtype, 1, any_pad, st);
+    return launch_attention_impl(q, k, vt, key_fill, nullptr, ctx, lse, B, H, T, Tp, operand_dtype, 1, any_pad, st);
 }
 
 static hipError_t launch_attention_impl(const void* q, const void* k, const void* vt, const float* key_bias,
@@ -352,14 +352,21 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const T* __restrict__ q
                                                           const float* __restrict__ lse,
                                                           const float* __restrict__ key_bias,
                                                           float* __restrict__ probs, int H, int Tlen,
-                                                          int layer, int Ltot) {
+                                                          int layer, int Ltot, int msa_C,
+                                                          const int* __restrict__ any_pad) {
+    // msa_C > 0: MSA column attention (axial_attention.py:207-218).  The "sequence" b is (batch, column),
+    // key_bias holds 0/1 masked_fill flags used when any_pad[0] != 0, query rows are NOT zeroed and the
+    // map goes to col_attentions[b_msa, layer, head, c, i, j] (msa_transformer.py:193-194).
     using V8 = typename Op<T>::v8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, lm = lane & 31;
-    const int bh = blockIdx.y;
+    const int nqb = (Tlen + 127) >> 7;
+    const int bh = blockIdx.x / nqb;  // 1-D grid: B*H can exceed the 65535 limit of grid.y (MSA columns)
     const int b = bh / H, head = bh - b * H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = (blockIdx.x - bh * nqb) * 128 + wave * 32;
     if (q0 >= Tlen) return;
+    const bool fill = msa_C > 0;
+    if (fill && (any_pad == nullptr || any_pad[0] == 0)) key_bias = nullptr;
 
     V8 qf[4];
     {
@@ -376,9 +383,13 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const T* __restrict__ q
         const int qr = q0 + mfma32_row(r, h);
         const int qc = min(qr, Tlen - 1);
         row_lse[r] = lse[(size_t)bh * Tlen + qc];
-        row_keep[r] = (key_bias != nullptr && key_bias[(size_t)b * Tlen + qc] != 0.f) ? 0.f : 1.f;
+        row_keep[r] = (!fill && key_bias != nullptr && key_bias[(size_t)b * Tlen + qc] != 0.f) ? 0.f : 1.f;
     }
     float* out = probs + (((size_t)b * Ltot + layer) * H + head) * (size_t)Tlen * Tlen;
+    if (fill) {
+        const int bm = b / msa_C, c = b - bm * msa_C;
+        out = probs + ((((size_t)bm * Ltot + layer) * H + head) * msa_C + c) * (size_t)Tlen * Tlen;
+    }
 
     for (int k0 = 0; k0 < Tlen; k0 += 32) {
         const int key = k0 + lm;
@@ -398,7 +409,8 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const T* __restrict__ q
             for (int r = 0; r < 16; ++r) {
                 const int qr = q0 + mfma32_row(r, h);
                 if (qr < Tlen) {
-                    const float p = __expf(s[r] + kb - row_lse[r]) * row_keep[r];
+                    const float sc = (fill && kb != 0.f) ? -10000.f : s[r] + kb;  // masked_fill vs additive -inf
+                    const float p = __expf(sc - row_lse[r]) * row_keep[r];
                     out[(size_t)qr * Tlen + key] = p;
                 }
             }
@@ -406,19 +418,33 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const T* __restrict__ q
     }
 }
 
+static hipError_t launch_probs_impl(const void* q, const void* k, const float* lse, const float* key_bias,
+                                    float* probs, int B, int H, int T, int layer, int num_layers_total,
+                                    int operand_dtype, int msa_C, const int* any_pad, hipStream_t st) {
+    dim3 grid((unsigned)(((T + 127) / 128) * B * H));
+    if (operand_dtype == ESMK_DT_BF16)
+        hipLaunchKernelGGL((attn_probs_kernel<__bf16>), grid, dim3(256), 0, st, (const __bf16*)q,
+                           (const __bf16*)k, lse, key_bias, probs, H, T, layer, num_layers_total, msa_C, any_pad);
+    else
+        hipLaunchKernelGGL((attn_probs_kernel<_Float16>), grid, dim3(256), 0, st,
+                           (const _Float16*)q, (const _Float16*)k, lse, key_bias, probs, H, T, layer,
+                           num_layers_total, msa_C, any_pad);
+    return hipGetLastError();
+}
+
 hipError_t launch_attention_probs(const void* q, const void* k, const float* lse,
                                   const float* key_bias, float* probs, int B, int H, int T,
                                   int layer, int num_layers_total, int operand_dtype,
                                   hipStream_t st) {
-    dim3 grid((T + 127) / 128, B * H);
-    if (operand_dtype == ESMK_DT_BF16)
-        hipLaunchKernelGGL((attn_probs_kernel<__bf16>), grid, dim3(256), 0, st, (const __bf16*)q,
-                           (const __bf16*)k, lse, key_bias, probs, H, T, layer, num_layers_total);
-    else
-        hipLaunchKernelGGL((attn_probs_kernel<_Float16>), grid, dim3(256), 0, st,
-                           (const _Float16*)q, (const _Float16*)k, lse, key_bias, probs, H, T, layer,
-                           num_layers_total);
-    return hipGetLastError();
+    return launch_probs_impl(q, k, lse, key_bias, probs, B, H, T, layer, num_layers_total, operand_dtype, 0,
+                             nullptr, st);
+}
+
+hipError_t launch_attention_probs_msa(const void* q, const void* k, const float* lse, const float* key_fill,
+                                      const int* any_pad, float* probs, int Bmsa, int C, int H, int R,
+                                      int layer, int num_layers_total, int operand_dtype, hipStream_t st) {
+    return launch_probs_impl(q, k, lse, key_fill, probs, Bmsa * C, H, R, layer, num_layers_total, operand_dtype,
+                             C, any_pad, st);
 }
 
 }  // namespace esmk

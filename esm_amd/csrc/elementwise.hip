@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                     typename Op<T>::v4 pk;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) pk[e] = Op<T>::from(o[e]);
-                    auto* dst = reinterpret_cast<typename Op<T>::v4*>(y + (size_t)row * E + c * 4);
+                    auto* dst = reinterpret_cast<typename Op<T>::v4*>(y + (size_t)row * (ex.ldy > 0 ? ex.ldy : E) + c * 4);
                     if constexpr (VAR & 2) __builtin_nontemporal_store(pk, dst);
                     else *dst = pk;
                 }
@@ -299,6 +299,58 @@ hipError_t launch_convert(const void* src, int src_dtype, void* dst, int dst_dty
     if (src_dtype == ESMK_DT_F32) return convert_from((const float*)src, dst, dst_dtype, n, st);
     if (src_dtype == ESMK_DT_F16) return convert_from((const _Float16*)src, dst, dst_dtype, n, st);
     if (src_dtype == ESMK_DT_BF16) return convert_from((const __bf16*)src, dst, dst_dtype, n, st);
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2-D parameter conversion with head-dim padding (load time only).  Models whose head_dim d is smaller
+// than the 64 the attention kernels are built for are packed as if every head had 64 dims: dim i of a head
+// goes to slot i (i < d/2) or 32 + (i - d/2), so that the rotary partner of slot c is slot c + 32 exactly as
+// for d = 64; the remaining slots are zero rows / columns and contribute nothing to q.k or to out_proj.
+//   map mode 0: identity;  1: index x = head * d + i  ->  head * 64 + slot(i)
+// ---------------------------------------------------------------------------------------------
+ESMK_DEV size_t head_pad_index(size_t x, int d) {
+    const size_t head = x / d;
+    const int i = (int)(x - head * d);
+    return head * 64 + (i < d / 2 ? i : 32 + (i - d / 2));
+}
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void convert2d_kernel(const S* __restrict__ src, D* __restrict__ dst,
+                                                         size_t rows, size_t cols, size_t dst_ld, int row_map,
+                                                         int col_map, int d) {
+    const size_t n = rows * cols;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        const size_t r = i / cols, c = i - r * cols;
+        const size_t rr = row_map ? head_pad_index(r, d) : r;
+        const size_t cc = col_map ? head_pad_index(c, d) : c;
+        dst[rr * dst_ld + cc] = (D)(float)src[i];
+    }
+}
+
+template <typename S>
+static hipError_t convert2d_from(const S* src, void* dst, int dst_dtype, size_t rows, size_t cols, size_t dst_ld,
+                                 int row_map, int col_map, int d, hipStream_t st) {
+    const unsigned blocks = (unsigned)std::min<size_t>((rows * cols + 255) / 256, 4096);
+#define ESMK_C2D(DT) \
+    hipLaunchKernelGGL((convert2d_kernel<S, DT>), dim3(blocks), dim3(256), 0, st, src, (DT*)dst, rows, cols, dst_ld, \
+                       row_map, col_map, d)
+    if (dst_dtype == ESMK_DT_F32) ESMK_C2D(float);
+    else if (dst_dtype == ESMK_DT_F16) ESMK_C2D(_Float16);
+    else if (dst_dtype == ESMK_DT_BF16) ESMK_C2D(__bf16);
+    else return hipErrorInvalidValue;
+#undef ESMK_C2D
+    return hipGetLastError();
+}
+
+hipError_t launch_convert2d(const void* src, int src_dtype, void* dst, int dst_dtype, size_t rows, size_t cols,
+                            size_t dst_ld, int row_map, int col_map, int d, hipStream_t st) {
+    if (rows * cols == 0) return hipSuccess;
+    if (src_dtype == ESMK_DT_F32) return convert2d_from((const float*)src, dst, dst_dtype, rows, cols, dst_ld, row_map, col_map, d, st);
+    if (src_dtype == ESMK_DT_F16) return convert2d_from((const _Float16*)src, dst, dst_dtype, rows, cols, dst_ld, row_map, col_map, d, st);
+    if (src_dtype == ESMK_DT_BF16) return convert2d_from((const __bf16*)src, dst, dst_dtype, rows, cols, dst_ld, row_map, col_map, d, st);
     return hipErrorInvalidValue;
 }
 

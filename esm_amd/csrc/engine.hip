@@ -55,6 +55,8 @@ struct MsaLayerOff {
 struct esmk_model {
     esmk_config cfg;
     int L, E, H, F, V, D;
+    int EA = 0;  // attention width inside the engine: H * 64 (heads with head_dim < 64 are spread over 64 slots)
+    int Kp = 0;  // E rounded up to the 64-wide K tile: row stride of the normalised activations
     // packed parameter image layout (byte offsets)
     size_t embed_f32, embed_op, fin_g, fin_b, lm_w, lm_b, lm_lng, lm_lnb, lm_bias, ct_w, ct_b;
     std::vector<LayerOff> layer;
@@ -96,13 +98,13 @@ struct Carve {
 
 void plan_packed(esmk_model* m) {
     const size_t os = op_size(m->cfg.operand_dtype);
-    const size_t E = m->E, F = m->F, V = m->V;
+    const size_t E = m->E, F = m->F, V = m->V, EA = m->EA, Kp = m->Kp;
     Carve c;
     m->embed_f32 = c.take(V * E * 4);
-    m->embed_op = c.take(V * E * os);
+    m->embed_op = c.take(V * Kp * os);
     m->fin_g = c.take(E * 4);
     m->fin_b = c.take(E * 4);
-    m->lm_w = c.take(E * E * os);
+    m->lm_w = c.take(E * Kp * os);
     m->lm_b = c.take(E * 4);
     m->lm_lng = c.take(E * 4);
     m->lm_lnb = c.take(E * 4);
@@ -112,11 +114,11 @@ void plan_packed(esmk_model* m) {
     m->layer.resize(m->L);
     for (int l = 0; l < m->L; ++l) {
         LayerOff& o = m->layer[l];
-        o.wqkv = c.take(3 * E * E * os);
-        o.bqkv = c.take(3 * E * 4);
-        o.wo = c.take(E * E * os);
+        o.wqkv = c.take(3 * EA * Kp * os);
+        o.bqkv = c.take(3 * EA * 4);
+        o.wo = c.take(E * EA * os);
         o.bo = c.take(E * 4);
-        o.w1 = c.take(F * E * os);
+        o.w1 = c.take(F * Kp * os);
         o.b1 = c.take(F * 4);
         o.w2 = c.take(E * F * os);
         o.b2 = c.take(E * 4);
@@ -179,15 +181,15 @@ struct Workspace {
 Workspace plan_workspace(const esmk_model* m, int B, int T, uint32_t flags) {
     Workspace w{};
     const size_t os = op_size(m->cfg.operand_dtype);
-    const size_t N = (size_t)B * T, E = m->E, F = m->F;
+    const size_t N = (size_t)B * T, E = m->E, F = m->F, EA = m->EA, Kp = m->Kp;
     w.Tp = (T + 63) / 64 * 64;
     Carve c;
     w.scale = c.take(B * 4);
     w.key_bias = c.take(N * 4);
     w.seq_info = c.take((size_t)B * 2 * 4);
     w.x = c.take(N * E * 4);
-    w.h = c.take(N * E * os);
-    const size_t qb = align_up(N * E * os);
+    w.h = c.take(N * std::max(Kp, EA) * os);
+    const size_t qb = align_up(N * EA * os);
     const size_t vtb = align_up((size_t)B * m->H * 64 * w.Tp * os);
     size_t big = 2 * qb + vtb;
     if (N * F * os > big) big = N * F * os;
@@ -210,7 +212,7 @@ int ensure_rope(esmk_model* m, int T, hipStream_t st) {
     if (T <= m->rope_cap) return 0;
     int cap = 1024;
     while (cap < T) cap *= 2;
-    const int half = m->D / 2;
+    const int half = 32;
     if (m->d_cos) {
         ESMK_TRY(hipStreamSynchronize(st));
         ESMK_TRY(hipFree(m->d_cos));
@@ -305,11 +307,12 @@ int esmk_create(const esmk_config* cfg, esmk_model** out) {
     if (cfg->operand_dtype != ESMK_F16 && cfg->operand_dtype != ESMK_BF16)
         return fail("esmk_create: operand_dtype must be ESMK_F16 or ESMK_BF16");
     const int d = cfg->embed_dim / cfg->num_heads;
-    if (d != 64)
+    if (d > 64 || d < 2 || (d & 1))
         return fail("esmk_create: head_dim " + std::to_string(d) +
-                    " is not supported by the gfx950 attention kernels (need 64)");
-    if (cfg->embed_dim % 32 != 0 || cfg->ffn_dim % 32 != 0)
-        return fail("esmk_create: embed_dim and ffn_dim must be multiples of 32");
+                    " is not supported by the gfx950 attention kernels (even head_dim <= 64; smaller heads are "
+                    "spread over 64 slots at pack time)");
+    if (cfg->embed_dim % 8 != 0 || cfg->ffn_dim % 64 != 0)
+        return fail("esmk_create: embed_dim must be a multiple of 8 and ffn_dim a multiple of 64");
     esmk_model* m = new esmk_model();
     m->cfg = *cfg;
     m->L = cfg->num_layers;
@@ -318,6 +321,8 @@ int esmk_create(const esmk_config* cfg, esmk_model** out) {
     m->F = cfg->ffn_dim;
     m->V = cfg->vocab;
     m->D = d;
+    m->EA = m->H * 64;
+    m->Kp = (m->E + 63) / 64 * 64;
     plan_packed(m);
     *out = m;
     return 0;
@@ -336,9 +341,11 @@ void esmk_destroy(esmk_model* m) {
 int esmk_set_rope_inv_freq(esmk_model* m, const float* inv_freq_host, int n) {
     if (!m || !inv_freq_host) return fail("esmk_set_rope_inv_freq: null argument");
     if (n != m->D / 2) return fail("esmk_set_rope_inv_freq: expected head_dim/2 values");
-    m->inv_freq.assign(inv_freq_host, inv_freq_host + n);
-    if (!m->d_inv_freq) ESMK_TRY(hipMalloc(&m->d_inv_freq, (size_t)n * 4));
-    ESMK_TRY(hipMemcpy(m->d_inv_freq, inv_freq_host, (size_t)n * 4, hipMemcpyHostToDevice));
+    // 32 slots: slot i < d/2 carries frequency i, the rest rotate by angle 0 (they only ever see zeros)
+    m->inv_freq.assign(32, 0.f);
+    for (int i = 0; i < n; ++i) m->inv_freq[i] = inv_freq_host[i];
+    if (!m->d_inv_freq) ESMK_TRY(hipMalloc(&m->d_inv_freq, 32 * 4));
+    ESMK_TRY(hipMemcpy(m->d_inv_freq, m->inv_freq.data(), 32 * 4, hipMemcpyHostToDevice));
     m->rope_cap = 0;  // tables are rebuilt on the next forward
     return 0;
 }
@@ -367,9 +374,22 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
         ESMK_TRY(launch_convert(src_dev, src_dtype, base + off, dst_dtype, n, st));
         return 0;
     };
+    // [rows, cols] matrix into a destination with row stride ld; rmap / cmap spread head_dim-d heads over
+    // 64 slots (elementwise.hip: head_pad_index).  The packed image is zero-initialised by the caller, so
+    // padded rows / columns stay zero.
+    const size_t EA = m->EA, Kp = m->Kp;
+    const int hd = m->D;
+    const int padmap = (hd != 64) ? 1 : 0;
+    auto put2d = [&](size_t off, int dst_dtype, size_t rows, size_t cols, size_t ld, int rmap, int cmap) -> int {
+        if (n != rows * cols)
+            return fail(std::string("esmk_pack_weight: ") + key + " has " + std::to_string(n) +
+                        " elements, expected " + std::to_string(rows * cols));
+        ESMK_TRY(launch_convert2d(src_dev, src_dtype, base + off, dst_dtype, rows, cols, ld, rmap, cmap, hd, st));
+        return 0;
+    };
     if (!strcmp(key, "embed_tokens.weight")) {
         if (put(m->embed_f32, ESMK_DT_F32, V * E)) return 1;
-        return put(m->embed_op, op, V * E);
+        return put2d(m->embed_op, op, V, E, Kp, 0, 0);
     }
     if (m->is_msa) {
         if (!strcmp(key, "embed_positions.weight")) return put(m->pos_emb, ESMK_DT_F32, (size_t)m->npos * E);
@@ -411,7 +431,7 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
     if (!strcmp(key, "lm_head.weight")) return 0;  // tied to embed_tokens.weight (esm2.py:71-75)
     if (!strcmp(key, "emb_layer_norm_after.weight")) return put(m->fin_g, ESMK_DT_F32, E);
     if (!strcmp(key, "emb_layer_norm_after.bias")) return put(m->fin_b, ESMK_DT_F32, E);
-    if (!strcmp(key, "lm_head.dense.weight")) return put(m->lm_w, op, E * E);
+    if (!strcmp(key, "lm_head.dense.weight")) return put2d(m->lm_w, op, E, E, Kp, 0, 0);
     if (!strcmp(key, "lm_head.dense.bias")) return put(m->lm_b, ESMK_DT_F32, E);
     if (!strcmp(key, "lm_head.layer_norm.weight")) return put(m->lm_lng, ESMK_DT_F32, E);
     if (!strcmp(key, "lm_head.layer_norm.bias")) return put(m->lm_lnb, ESMK_DT_F32, E);
@@ -426,15 +446,17 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
             return fail(std::string("esmk_pack_weight: bad layer index in ") + key);
         const char* sub = end + 1;
         const LayerOff& o = m->layer[l];
-        if (!strcmp(sub, "self_attn.q_proj.weight")) return put(o.wqkv, op, E * E);
-        if (!strcmp(sub, "self_attn.k_proj.weight")) return put(o.wqkv + E * E * os, op, E * E);
-        if (!strcmp(sub, "self_attn.v_proj.weight")) return put(o.wqkv + 2 * E * E * os, op, E * E);
-        if (!strcmp(sub, "self_attn.q_proj.bias")) return put(o.bqkv, ESMK_DT_F32, E);
-        if (!strcmp(sub, "self_attn.k_proj.bias")) return put(o.bqkv + E * 4, ESMK_DT_F32, E);
-        if (!strcmp(sub, "self_attn.v_proj.bias")) return put(o.bqkv + 2 * E * 4, ESMK_DT_F32, E);
-        if (!strcmp(sub, "self_attn.out_proj.weight")) return put(o.wo, op, E * E);
+        // q/k/v: output rows are head dims -> spread over 64 slots; input columns padded to Kp
+        if (!strcmp(sub, "self_attn.q_proj.weight")) return put2d(o.wqkv, op, E, E, Kp, padmap, 0);
+        if (!strcmp(sub, "self_attn.k_proj.weight")) return put2d(o.wqkv + EA * Kp * os, op, E, E, Kp, padmap, 0);
+        if (!strcmp(sub, "self_attn.v_proj.weight")) return put2d(o.wqkv + 2 * EA * Kp * os, op, E, E, Kp, padmap, 0);
+        if (!strcmp(sub, "self_attn.q_proj.bias")) return put2d(o.bqkv, ESMK_DT_F32, 1, E, EA, 0, padmap);
+        if (!strcmp(sub, "self_attn.k_proj.bias")) return put2d(o.bqkv + EA * 4, ESMK_DT_F32, 1, E, EA, 0, padmap);
+        if (!strcmp(sub, "self_attn.v_proj.bias")) return put2d(o.bqkv + 2 * EA * 4, ESMK_DT_F32, 1, E, EA, 0, padmap);
+        // out_proj consumes the attention context: its input columns follow the same slot layout
+        if (!strcmp(sub, "self_attn.out_proj.weight")) return put2d(o.wo, op, E, E, EA, 0, padmap);
         if (!strcmp(sub, "self_attn.out_proj.bias")) return put(o.bo, ESMK_DT_F32, E);
-        if (!strcmp(sub, "fc1.weight")) return put(o.w1, op, F * E);
+        if (!strcmp(sub, "fc1.weight")) return put2d(o.w1, op, F, E, Kp, 0, 0);
         if (!strcmp(sub, "fc1.bias")) return put(o.b1, ESMK_DT_F32, F);
         if (!strcmp(sub, "fc2.weight")) return put(o.w2, op, E * F);
         if (!strcmp(sub, "fc2.bias")) return put(o.b2, ESMK_DT_F32, E);
@@ -477,7 +499,7 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
     hipStream_t st = (hipStream_t)stream;
     const int op = m->cfg.operand_dtype;
     const size_t os = op_size(op);
-    const int N = B * T, E = m->E, F = m->F, H = m->H, L = m->L;
+    const int N = B * T, E = m->E, F = m->F, H = m->H, L = m->L, EA = m->EA, Kp = m->Kp;
     char* ws = (char*)workspace_dev;
     const char* pk = (const char*)packed_dev;
     float* scale = (float*)(ws + w.scale);
@@ -518,9 +540,13 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
     };
     auto lnorm = [&](const float* in, size_t go, size_t bo, void* y, float* y32) -> int {
         ProfScope ps(m, st, PC_LAYERNORM, 8 * NE, NE * (4 + (y ? os : 0) + (y32 ? 4 : 0)));
-        ESMK_TRY(launch_layernorm(in, (const float*)(pk + go), (const float*)(pk + bo), y, y32, N, E, op, st));
+        LnExtra ex;
+        ex.ldy = Kp;  // normalised rows are K operands: row stride = E rounded up to the 64-wide K tile
+        ESMK_TRY(launch_layernorm_ex(in, (const float*)(pk + go), (const float*)(pk + bo), y, y32, N, E, op, ex, st));
         return 0;
     };
+    // pad columns [E, Kp) of the activation rows must be finite (they meet zero weight columns)
+    if (Kp != E) ESMK_TRY(hipMemsetAsync(h, 0, (size_t)N * std::max(Kp, EA) * os, st));
 
     // esm2.py:82-95
     {
@@ -544,8 +570,8 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.W = pk + o.wqkv;
         g.bias = (const float*)(pk + o.bqkv);
         g.M = N;
-        g.N = 2 * E;
-        g.K = E;
+        g.N = 2 * EA;
+        g.K = Kp;
         g.q = q;
         g.k = k;
         g.vt = vt;
@@ -553,13 +579,13 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.sin = m->d_sin;
         g.T = T;
         g.H = H;
-        g.E = E;
+        g.E = EA;
         g.Tp = w.Tp;
         g.scaling = 1.0f / sqrtf((float)m->D);
-        if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;  // q, k: weight rows [0,2E)
-        g.W = pk + o.wqkv + (size_t)2 * E * E * os;             // v: weight rows [2E,3E)
-        g.bias = (const float*)(pk + o.bqkv) + 2 * E;
-        g.N = E;
+        if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;  // q, k: weight rows [0,2EA)
+        g.W = pk + o.wqkv + (size_t)2 * EA * Kp * os;           // v: weight rows [2EA,3EA)
+        g.bias = (const float*)(pk + o.bqkv) + 2 * EA;
+        g.N = EA;
         if (gemm(PC_GEMM_QKV, g, EPI_V_T, os)) return 1;
         {
             // 4 T d flop per (query, head) pair: QK^T and PV; q,k,v read + ctx written
@@ -578,7 +604,7 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.out = x;
         g.M = N;
         g.N = E;
-        g.K = E;
+        g.K = EA;
         if (gemm(PC_GEMM_OUT, g, EPI_RESID_F32, 8)) return 1;
         if (lnorm(x, o.ln2g, o.ln2b, h, nullptr)) return 1;
         g = GemmArgs();
@@ -588,7 +614,7 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.out = ffn;
         g.M = N;
         g.N = F;
-        g.K = E;
+        g.K = Kp;
         if (gemm(PC_GEMM_FC1, g, EPI_GELU_T, os)) return 1;
         g = GemmArgs();
         g.A = ffn;
@@ -623,7 +649,7 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.out = g32;
         g.M = N;
         g.N = E;
-        g.K = E;
+        g.K = Kp;
         if (gemm(PC_LM_DENSE, g, EPI_GELU_F32, 4)) return 1;
         if (lnorm(g32, m->lm_lng, m->lm_lnb, h, nullptr)) return 1;
         g = GemmArgs();
@@ -633,7 +659,7 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.out = logits_out_dev;
         g.M = N;
         g.N = m->V;
-        g.K = E;
+        g.K = Kp;
         if (gemm(PC_LM_LOGITS, g, EPI_STORE_F32, 4)) return 1;
     }
     if (want_contacts) {  // esm2.py:140-142 -> modules.py:338-357
@@ -724,6 +750,7 @@ int esmk_op_qkv_rope(esmk_model* m, const void* a_dev, const void* wqkv_dev,
                      const float* bias_dev, void* q_out, void* k_out, void* vt_out, int B, int T,
                      void* stream) {
     if (!m) return fail("esmk_op_qkv_rope: null model");
+    if (m->D != 64 || m->Kp != m->E) return fail("esmk_op_qkv_rope: single-op entry point needs head_dim 64");
     hipStream_t st = (hipStream_t)stream;
     if (ensure_rope(m, T, st)) return 1;
     const int Tp = (T + 63) / 64 * 64;
@@ -788,7 +815,7 @@ int esmk_op_contacts(const float* attn_dev, const int64_t* tokens_dev, const flo
 namespace {
 
 struct MsaWorkspace {
-    size_t keep, col_fill, any_pad, x, h, big, scores, probs, ct_scratch, total;
+    size_t keep, col_fill, any_pad, x, h, big, scores, probs, lse, ct_scratch, total;
     size_t q, k, vt;  // inside big
     int Cp, Rp;
 };
@@ -817,6 +844,7 @@ MsaWorkspace plan_msa_workspace(const esmk_model* m, int B, int R, int C, uint32
     w.vt = w.big + 2 * qb;
     w.scores = c.take((size_t)B * H * C * w.Cp * 4);
     w.probs = c.take((size_t)B * H * C * w.Cp * os);
+    w.lse = c.take((flags & ESMK_OUT_COL_ATTN) ? (size_t)B * C * H * R * 4 : 0);
     const int S = C - (m->cfg.prepend_bos ? 1 : 0) - (m->cfg.append_eos ? 1 : 0);
     w.ct_scratch =
         c.take((flags & ESMK_OUT_CONTACTS) ? (size_t)B * m->L * m->H * (size_t)(S > 0 ? S + 1 : 1) * 4 : 0);
@@ -859,6 +887,8 @@ int esmk_msa_create(const esmk_msa_config* cfg, esmk_model** out) {
     m->F = cfg->ffn_dim;
     m->V = cfg->vocab;
     m->D = 64;
+    m->EA = m->E;
+    m->Kp = m->E;
     m->is_msa = true;
     m->npos = cfg->num_positions;
     m->has_msa_pos = cfg->has_msa_position_embedding;
@@ -876,8 +906,8 @@ int esmk_msa_workspace_bytes(const esmk_model* m, int B, int R, int C, uint32_t 
 
 int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_dev, int B, int R, int C,
                      const int32_t* repr_layers, int n_repr, void* const* repr_out_dev, uint32_t out_flags,
-                     void* logits_out_dev, void* row_attn_out_dev, void* contacts_out_dev,
-                     void* workspace_dev, size_t workspace_bytes, void* stream) {
+                     void* logits_out_dev, void* row_attn_out_dev, void* col_attn_out_dev,
+                     void* contacts_out_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
     if (!m || !m->is_msa) return fail("esmk_msa_forward: not an MSA model handle");
     if (!packed_dev || !tokens_dev || !workspace_dev) return fail("esmk_msa_forward: null argument");
     if (B <= 0 || R <= 0 || C <= 0) return fail("esmk_msa_forward: B, R, C must be positive");
@@ -892,6 +922,8 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
     if (want_logits && !logits_out_dev) return fail("esmk_msa_forward: logits buffer missing");
     if (want_attn && !row_attn_out_dev) return fail("esmk_msa_forward: row attention buffer missing");
     if (want_contacts && !contacts_out_dev) return fail("esmk_msa_forward: contacts buffer missing");
+    const bool want_col = out_flags & ESMK_OUT_COL_ATTN;
+    if (want_col && !col_attn_out_dev) return fail("esmk_msa_forward: column attention buffer missing");
     for (int i = 0; i < n_repr; ++i)
         if (repr_layers[i] < 0 || repr_layers[i] > m->L || !repr_out_dev[i])
             return fail("esmk_msa_forward: bad repr layer request");
@@ -1047,7 +1079,11 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
         }
         if (Rp != R) ESMK_TRY(hipMemsetAsync(vt, 0, (size_t)B * C * H * 64 * Rp * os, st));
         if (qkv(o.col, R, Rp, 1.0f / sqrtf(64.0f), nullptr, 0)) return 1;
-        ESMK_TRY(launch_attention_fill(q, k, vt, col_fill, any_pad, h, B * C, H, R, Rp, op, st));
+        float* lse = want_col ? (float*)(ws + w.lse) : nullptr;
+        ESMK_TRY(launch_attention_fill(q, k, vt, col_fill, any_pad, h, lse, B * C, H, R, Rp, op, st));
+        if (want_col)
+            ESMK_TRY(launch_attention_probs_msa(q, k, lse, col_fill, any_pad, (float*)col_attn_out_dev, B, C, H, R, l,
+                                                L, op, st));
         if (out_proj(o.col, R, C)) return 1;
 
         // ---- feed forward (modules.py:395-418) ----

@@ -75,6 +75,7 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
 struct LnExtra {
     const float* row_keep = nullptr;
     int map_R = 0, map_C = 0;
+    int ldy = 0;  // row stride of the operand-dtype output in elements (0 = E): K-padded activation rows
 };
 hipError_t launch_layernorm_ex(const float* x, const float* gamma, const float* beta, void* y,
                                float* y32, int rows, int E, int operand_dtype, LnExtra ex,
@@ -90,6 +91,9 @@ hipError_t launch_msa_row_softmax(const float* scores, const float* keep, const 
 // dtype conversion of a parameter tensor into the packed image
 hipError_t launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype, size_t n,
                           hipStream_t st);
+// [rows, cols] -> dst with row stride dst_ld; row_map / col_map = 1 spreads head_dim-d heads over 64 slots
+hipError_t launch_convert2d(const void* src, int src_dtype, void* dst, int dst_dtype, size_t rows, size_t cols,
+                            size_t dst_ld, int row_map, int col_map, int d, hipStream_t st);
 // RoPE tables cos/sin[t][i] = cos/sin(t * inv_freq[i]) (rotary_embedding.py:47-61), fp32
 hipError_t launch_rope_table(const float* inv_freq, float* cos, float* sin, int T, int half,
                              hipStream_t st);
@@ -106,8 +110,12 @@ hipError_t launch_attention(const void* q, const void* k, const void* vt, const 
 // same kernel, MSA column attention: key_fill[b,t] != 0 REPLACES the score by -10000 (masked_fill,
 // axial_attention.py:211-215) and is only applied when any_pad[0] != 0
 hipError_t launch_attention_fill(const void* q, const void* k, const void* vt, const float* key_fill,
-                                 const int* any_pad, void* ctx, int B, int H, int T, int Tp,
+                                 const int* any_pad, void* ctx, float* lse, int B, int H, int T, int Tp,
                                  int operand_dtype, hipStream_t st);
+// col_attentions[b, layer, h, c, i, j] (msa_transformer.py:193-194) from q, k and the saved log-sum-exp
+hipError_t launch_attention_probs_msa(const void* q, const void* k, const float* lse, const float* key_fill,
+                                      const int* any_pad, float* probs, int Bmsa, int C, int H, int R,
+                                      int layer, int num_layers_total, int operand_dtype, hipStream_t st);
 hipError_t launch_attention_probs(const void* q, const void* k, const float* lse,
                                   const float* key_bias, float* probs, int B, int H, int T,
                                   int layer, int num_layers_total, int operand_dtype,

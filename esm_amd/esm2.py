@@ -114,7 +114,8 @@ class _Engine:
             N.check(N.lib.esmk_set_rope_inv_freq(self.handle, arr, len(inv)))
             nbytes = ctypes.c_size_t()
             N.check(N.lib.esmk_packed_bytes(self.handle, ctypes.byref(nbytes)))
-            self.packed = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+            # zero-initialised: padded head slots / K columns of the packed image must stay zero
+            self.packed = torch.zeros(nbytes.value, dtype=torch.uint8, device=device)
         self.fingerprint = None
         self.workspace = None
         self._named = None

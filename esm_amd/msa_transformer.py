@@ -8,8 +8,9 @@ Sub-modules are parameter containers; the axial layer math (tied row attention, 
 reference esm/axial_attention.py, esm/modules.py:145-221,360-418) runs inside ``esmk_msa_forward``.
 There is no CPU path.
 
-Deviation: ``col_attentions [B,L,H,C,R,R]`` are not materialised (58 GB for a 128x513 MSA);
-``need_head_weights`` returns ``row_attentions`` (and ``contacts``) only.
+``need_head_weights=True`` returns ``row_attentions [B,L,H,C,C]`` and ``col_attentions [B,L,H,C,R,R]`` as the
+reference does (the latter is 58 GB in fp32 for a 12-layer 128x513 MSA: it fits the MI355X's 288 GB).  Set
+``model.return_col_attentions = False`` to skip it, e.g. for ``predict_contacts`` on deep MSAs.
 """
 import ctypes
 
@@ -168,6 +169,7 @@ class MSATransformer(nn.Module):
         self.emb_layer_norm_after = nn.LayerNorm(E)
         self.lm_head = RobertaLMHead(E, self.alphabet_size, self.embed_tokens.weight)
         self._engine = None
+        self.return_col_attentions = True
 
     @property
     def num_layers(self):
@@ -219,10 +221,13 @@ class MSATransformer(nn.Module):
             f32 = dict(dtype=torch.float32, device=dev)
             logits = torch.empty((B, R, C, V), **f32)
             reps = [torch.empty((B, R, C, E), **f32) for _ in repr_set]
-            row_attn = contacts = None
+            row_attn = col_attn = contacts = None
             if need_head_weights:
                 flags |= N.OUT_ATTN
                 row_attn = torch.empty((B, L, H, C, C), **f32)
+                if self.return_col_attentions:
+                    flags |= N.OUT_COL_ATTN
+                    col_attn = torch.empty((B, L, H, C, R, R), **f32)
             if return_contacts:
                 flags |= N.OUT_CONTACTS
                 S = C - int(self.prepend_bos) - int(self.append_eos)
@@ -232,11 +237,13 @@ class MSATransformer(nn.Module):
             outs_arr = (ctypes.c_void_p * max(1, len(repr_set)))(*[r.data_ptr() for r in reps])
             N.check(N.lib.esmk_msa_forward(
                 eng.handle, N.ptr(eng.packed), N.ptr(tok), B, R, C, layers_arr, len(repr_set), outs_arr, flags,
-                N.ptr(logits), N.ptr(row_attn), N.ptr(contacts), N.ptr(ws), ws.numel(), N.cur_stream()))
+                N.ptr(logits), N.ptr(row_attn), N.ptr(col_attn), N.ptr(contacts), N.ptr(ws), ws.numel(), N.cur_stream()))
         out_dt = w.dtype
         cast = (lambda t: t) if out_dt == torch.float32 else (lambda t: t.to(out_dt))
         result = {"logits": cast(logits), "representations": {l: cast(r) for l, r in zip(repr_set, reps)}}
         if need_head_weights:
+            if col_attn is not None:
+                result["col_attentions"] = cast(col_attn)
             result["row_attentions"] = cast(row_attn)
             if return_contacts:
                 result["contacts"] = cast(contacts)

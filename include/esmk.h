@@ -32,7 +32,8 @@ enum { ESMK_F32 = 0, ESMK_F16 = 1, ESMK_BF16 = 2 };
 enum {
     ESMK_OUT_LOGITS = 1u,   /* logits [B,T,V] fp32                       (esm2.py:129)      */
     ESMK_OUT_ATTN = 2u,     /* attentions [B,L,H,T,T] fp32               (esm2.py:132-139)  */
-    ESMK_OUT_CONTACTS = 4u  /* contacts [B,T-2,T-2] fp32                 (esm2.py:140-142)  */
+    ESMK_OUT_CONTACTS = 4u, /* contacts [B,T-2,T-2] fp32                 (esm2.py:140-142)  */
+    ESMK_OUT_COL_ATTN = 8u  /* esmk_msa_forward: col_attentions [B,L,H,C,R,R] fp32 (msa_transformer.py:193-194) */
 };
 
 typedef struct esmk_model esmk_model;
@@ -121,12 +122,12 @@ int esmk_msa_workspace_bytes(const esmk_model* m, int B, int R, int C, uint32_t 
  *   repr_out_dev[i]  fp32 [B,R,C,E]
  *   logits_out_dev   fp32 [B,R,C,V]        (iff ESMK_OUT_LOGITS)
  *   row_attn_out_dev fp32 [B,L,H,C,C]      (iff ESMK_OUT_ATTN or ESMK_OUT_CONTACTS)
- *   contacts_out_dev fp32 [B,C-1,C-1]      (iff ESMK_OUT_CONTACTS)
- * col_attentions [B,L,H,C,R,R] are not produced by this entry point. */
+ *   col_attn_out_dev fp32 [B,L,H,C,R,R]    (iff ESMK_OUT_COL_ATTN; 4.8 GB per layer for a 128 x 513 MSA)
+ *   contacts_out_dev fp32 [B,C-1,C-1]      (iff ESMK_OUT_CONTACTS) */
 int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_dev, int B, int R, int C,
                      const int32_t* repr_layers, int n_repr, void* const* repr_out_dev, uint32_t out_flags,
-                     void* logits_out_dev, void* row_attn_out_dev, void* contacts_out_dev,
-                     void* workspace_dev, size_t workspace_bytes, void* stream);
+                     void* logits_out_dev, void* row_attn_out_dev, void* col_attn_out_dev,
+                     void* contacts_out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* Per-kernel-class timing of esmk_forward with HIP events recorded on the launch stream
  * (measurement support for bench.py; the reference has no counterpart).

@@ -49,6 +49,8 @@ def test_msa_engine_matches_reference_fixture(path):
         assert e < REL, (layer, e)
     assert rel_err(out["logits"].cpu(), fix["logits"]) < REL
     assert (out["row_attentions"].cpu() - fix["row_attentions"]).abs().max().item() < 2e-3
+    assert out["col_attentions"].shape == fix["col_attentions"].shape
+    assert (out["col_attentions"].cpu() - fix["col_attentions"]).abs().max().item() < 2e-3
     assert (out["contacts"].cpu() - fix["contacts"]).abs().max().item() < 5e-3
     assert out["contacts"].shape == fix["contacts"].shape
 
@@ -70,6 +72,7 @@ def test_msa_engine_matches_oracle_at_100M_dims(B, R, C, pads):
     # tied row attention sums R*64 fp16 products per score: the probability error grows with the MSA depth
     # (measured 3.5e-3 at R = 128 on sharp synthetic attention maps)
     assert (out["row_attentions"].cpu() - ref["row_attentions"]).abs().max().item() < (2e-3 if R <= 32 else 6e-3)
+    assert (out["col_attentions"].cpu() - ref["col_attentions"]).abs().max().item() < 2e-3
     assert (out["contacts"].cpu() - ref["contacts"]).abs().max().item() < 5e-3
 
 
@@ -81,6 +84,7 @@ def test_msa_config5_full_size_properties():
 
     L, E, H, F = MSA_DIMS["esm_msa1b_t12_100M_UR50S"]
     model, _ = build(L, E, H, F, seed=41)
+    model.return_col_attentions = False  # 58 GB at this size; covered by the smaller cases
     toks = synth_msa_tokens(1, 128, 513, seed=7).cuda()
     with torch.no_grad():
         out = model(toks, repr_layers=[L], return_contacts=True)
