@@ -312,6 +312,11 @@ hipError_t launch_convert(const void* src, int src_dtype, void* dst, int dst_dty
 ESMK_DEV size_t head_pad_index(size_t x, int d) {
     const size_t head = x / d;
     const int i = (int)(x - head * d);
+    if (d == 128) {
+        // q/k rows of a 128-wide head in the QKV epilogue's slice order: dims [0,32) | [64,96) | [32,64) | [96,128)
+        const int half = i >> 6, j = i & 63;
+        return head * 128 + (j >> 5) * 64 + half * 32 + (j & 31);
+    }
     return head * 64 + (i < d / 2 ? i : 32 + (i - d / 2));
 }
 

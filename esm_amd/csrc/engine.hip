@@ -190,7 +190,7 @@ Workspace plan_workspace(const esmk_model* m, int B, int T, uint32_t flags) {
     w.x = c.take(N * E * 4);
     w.h = c.take(N * std::max(Kp, EA) * os);
     const size_t qb = align_up(N * EA * os);
-    const size_t vtb = align_up((size_t)B * m->H * 64 * w.Tp * os);
+    const size_t vtb = align_up((size_t)B * EA * w.Tp * os);
     size_t big = 2 * qb + vtb;
     if (N * F * os > big) big = N * F * os;
     if (N * E * 4 > big) big = N * E * 4;
@@ -212,7 +212,7 @@ int ensure_rope(esmk_model* m, int T, hipStream_t st) {
     if (T <= m->rope_cap) return 0;
     int cap = 1024;
     while (cap < T) cap *= 2;
-    const int half = 32;
+    const int half = m->D == 128 ? 64 : 32;
     if (m->d_cos) {
         ESMK_TRY(hipStreamSynchronize(st));
         ESMK_TRY(hipFree(m->d_cos));
@@ -307,10 +307,10 @@ int esmk_create(const esmk_config* cfg, esmk_model** out) {
     if (cfg->operand_dtype != ESMK_F16 && cfg->operand_dtype != ESMK_BF16)
         return fail("esmk_create: operand_dtype must be ESMK_F16 or ESMK_BF16");
     const int d = cfg->embed_dim / cfg->num_heads;
-    if (d > 64 || d < 2 || (d & 1))
+    if ((d > 64 && d != 128) || d < 2 || (d & 1))
         return fail("esmk_create: head_dim " + std::to_string(d) +
-                    " is not supported by the gfx950 attention kernels (even head_dim <= 64; smaller heads are "
-                    "spread over 64 slots at pack time)");
+                    " is not supported by the gfx950 attention kernels (128, or an even head_dim <= 64; smaller "
+                    "heads are spread over 64 slots at pack time)");
     if (cfg->embed_dim % 8 != 0 || cfg->ffn_dim % 64 != 0)
         return fail("esmk_create: embed_dim must be a multiple of 8 and ffn_dim a multiple of 64");
     esmk_model* m = new esmk_model();
@@ -321,7 +321,7 @@ int esmk_create(const esmk_config* cfg, esmk_model** out) {
     m->F = cfg->ffn_dim;
     m->V = cfg->vocab;
     m->D = d;
-    m->EA = m->H * 64;
+    m->EA = m->H * (d == 128 ? 128 : 64);
     m->Kp = (m->E + 63) / 64 * 64;
     plan_packed(m);
     *out = m;
@@ -341,11 +341,13 @@ void esmk_destroy(esmk_model* m) {
 int esmk_set_rope_inv_freq(esmk_model* m, const float* inv_freq_host, int n) {
     if (!m || !inv_freq_host) return fail("esmk_set_rope_inv_freq: null argument");
     if (n != m->D / 2) return fail("esmk_set_rope_inv_freq: expected head_dim/2 values");
-    // 32 slots: slot i < d/2 carries frequency i, the rest rotate by angle 0 (they only ever see zeros)
-    m->inv_freq.assign(32, 0.f);
+    // 32 slots (64 for head_dim 128): slot i < d/2 carries frequency i, the rest rotate by angle 0 (they only
+    // ever see zeros)
+    const int slots = m->D == 128 ? 64 : 32;
+    m->inv_freq.assign(slots, 0.f);
     for (int i = 0; i < n; ++i) m->inv_freq[i] = inv_freq_host[i];
-    if (!m->d_inv_freq) ESMK_TRY(hipMalloc(&m->d_inv_freq, 32 * 4));
-    ESMK_TRY(hipMemcpy(m->d_inv_freq, m->inv_freq.data(), 32 * 4, hipMemcpyHostToDevice));
+    if (!m->d_inv_freq) ESMK_TRY(hipMalloc(&m->d_inv_freq, (size_t)slots * 4));
+    ESMK_TRY(hipMemcpy(m->d_inv_freq, m->inv_freq.data(), (size_t)slots * 4, hipMemcpyHostToDevice));
     m->rope_cap = 0;  // tables are rebuilt on the next forward
     return 0;
 }
@@ -379,7 +381,8 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
     // padded rows / columns stay zero.
     const size_t EA = m->EA, Kp = m->Kp;
     const int hd = m->D;
-    const int padmap = (hd != 64) ? 1 : 0;
+    const int padmap = (hd < 64) ? 1 : 0;        // q, k, v, out_proj: heads spread over 64 slots
+    const int qkmap = (hd != 64) ? 1 : 0;        // q, k additionally: slice order of 128-wide heads
     auto put2d = [&](size_t off, int dst_dtype, size_t rows, size_t cols, size_t ld, int rmap, int cmap) -> int {
         if (n != rows * cols)
             return fail(std::string("esmk_pack_weight: ") + key + " has " + std::to_string(n) +
@@ -447,11 +450,11 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
         const char* sub = end + 1;
         const LayerOff& o = m->layer[l];
         // q/k/v: output rows are head dims -> spread over 64 slots; input columns padded to Kp
-        if (!strcmp(sub, "self_attn.q_proj.weight")) return put2d(o.wqkv, op, E, E, Kp, padmap, 0);
-        if (!strcmp(sub, "self_attn.k_proj.weight")) return put2d(o.wqkv + EA * Kp * os, op, E, E, Kp, padmap, 0);
+        if (!strcmp(sub, "self_attn.q_proj.weight")) return put2d(o.wqkv, op, E, E, Kp, qkmap, 0);
+        if (!strcmp(sub, "self_attn.k_proj.weight")) return put2d(o.wqkv + EA * Kp * os, op, E, E, Kp, qkmap, 0);
         if (!strcmp(sub, "self_attn.v_proj.weight")) return put2d(o.wqkv + 2 * EA * Kp * os, op, E, E, Kp, padmap, 0);
-        if (!strcmp(sub, "self_attn.q_proj.bias")) return put2d(o.bqkv, ESMK_DT_F32, 1, E, EA, 0, padmap);
-        if (!strcmp(sub, "self_attn.k_proj.bias")) return put2d(o.bqkv + EA * 4, ESMK_DT_F32, 1, E, EA, 0, padmap);
+        if (!strcmp(sub, "self_attn.q_proj.bias")) return put2d(o.bqkv, ESMK_DT_F32, 1, E, EA, 0, qkmap);
+        if (!strcmp(sub, "self_attn.k_proj.bias")) return put2d(o.bqkv + EA * 4, ESMK_DT_F32, 1, E, EA, 0, qkmap);
         if (!strcmp(sub, "self_attn.v_proj.bias")) return put2d(o.bqkv + 2 * EA * 4, ESMK_DT_F32, 1, E, EA, 0, padmap);
         // out_proj consumes the attention context: its input columns follow the same slot layout
         if (!strcmp(sub, "self_attn.out_proj.weight")) return put2d(o.wo, op, E, E, EA, 0, padmap);
@@ -563,7 +566,7 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         const LayerOff& o = m->layer[l];
         // keys in [T,Tp) of V^T get probability exactly 0 but must be finite; the region is
         // shared with the FFN intermediate, so it is cleared every layer (odd T only).
-        if (w.Tp != T) ESMK_TRY(hipMemsetAsync(vt, 0, (size_t)B * H * 64 * w.Tp * os, st));
+        if (w.Tp != T) ESMK_TRY(hipMemsetAsync(vt, 0, (size_t)B * EA * w.Tp * os, st));
         if (lnorm(x, o.ln1g, o.ln1b, h, nullptr)) return 1;
         g = GemmArgs();
         g.A = h;
@@ -582,6 +585,7 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.E = EA;
         g.Tp = w.Tp;
         g.scaling = 1.0f / sqrtf((float)m->D);
+        g.head_dim = m->D == 128 ? 128 : 64;
         if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;  // q, k: weight rows [0,2EA)
         g.W = pk + o.wqkv + (size_t)2 * EA * Kp * os;           // v: weight rows [2EA,3EA)
         g.bias = (const float*)(pk + o.bqkv) + 2 * EA;
@@ -590,12 +594,15 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         {
             // 4 T d flop per (query, head) pair: QK^T and PV; q,k,v read + ctx written
             ProfScope ps(m, st, PC_ATTENTION, 4.0 * N * (double)T * E, 4 * NE * os);
-            ESMK_TRY(launch_attention(q, k, vt, key_bias, seq_info, h, lse, B, H, T, w.Tp, op, st));
+            if (m->D == 128) ESMK_TRY(launch_attention128(q, k, vt, key_bias, seq_info, h, lse, B, H, T, w.Tp, op, st));
+            else ESMK_TRY(launch_attention(q, k, vt, key_bias, seq_info, h, lse, B, H, T, w.Tp, op, st));
         }
         if (want_attn) {
             ProfScope ps(m, st, PC_ATTN_PROBS, 2.0 * N * (double)T * E, 2 * NE * os + 4.0 * N * T * H);
-            ESMK_TRY(launch_attention_probs(q, k, lse, key_bias, (float*)attn_out_dev, B, H, T, l, L,
-                                            op, st));
+            if (m->D == 128)
+                ESMK_TRY(launch_attention_probs128(q, k, lse, key_bias, (float*)attn_out_dev, B, H, T, l, L, op, st));
+            else
+                ESMK_TRY(launch_attention_probs(q, k, lse, key_bias, (float*)attn_out_dev, B, H, T, l, L, op, st));
         }
         g = GemmArgs();
         g.A = h;

@@ -115,14 +115,16 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
 
     if constexpr (EPI == EPI_V_T) {
         // vt[b][head][dv][Tp], keys permuted inside groups of 16 (4-groups 1 and 2 swapped)
-        const int head = n_base >> 6;
+        const int hd = GEN ? p.head_dim : 64;   // 128: the wave's 64 columns are one half of a head
+        const int head = n_base / hd;
+        const int dv0 = n_base - head * hd;
         T* vt = reinterpret_cast<T*>(p.vt);
         const float bv0 = p.bias[n_base + lm], bv1 = p.bias[n_base + 32 + lm];
         const bool aligned = FULL || (p.T % 32 == 0);  // a 32-token piece = one aligned run of one sequence
         const bool perm = !GEN || (p.vt_rows == 0);  // ESM-2 attention consumes permuted keys, the MSA context GEMM plain ones
         // row index of vt for sequence `sq`: ESM-2 [B,H,64,Tp]; MSA row attention [B,H,R,64,Tp], sq = (b,r)
         auto vt_row0 = [&](int sq) -> size_t {
-            if (!GEN || p.vt_rows == 0) return (size_t)(sq * p.H + head) * 64;
+            if (!GEN || p.vt_rows == 0) return (size_t)(sq * p.H + head) * hd + dv0;
             const int bm = sq / p.vt_rows, r = sq - bm * p.vt_rows;
             return ((size_t)(bm * p.H + head) * p.vt_rows + r) * 64;
         };
@@ -181,7 +183,13 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
     } else if constexpr (EPI == EPI_QKV_ROPE) {
         // q and k projections (N = 2E): the wave's 64 columns are exactly one head (head_dim 64)
         const int which = n_base / p.E;  // 0 q, 1 k (wave uniform)
-        const int head = (n_base - which * p.E) >> 6;
+        // head_dim 128: a head is two 64-column slices; the weights are packed so that slice sl holds dims
+        // [32 sl, 32 sl + 32) and their rotary partners 64 further up, i.e. the partner of column c is c + 32
+        const int hd = GEN ? p.head_dim : 64;
+        const int hrem = n_base - which * p.E;
+        const int head = hrem / hd;
+        const int sl = (hrem - head * hd) >> 6;
+        const int rope_ld = hd >> 1;
         T* qk = reinterpret_cast<T*>(which == 0 ? p.q : p.k);
         const float sc = which == 0 ? p.scaling : 1.0f;
 #pragma unroll
@@ -193,8 +201,8 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = 8 * g + 4 * h;  // first of 4 consecutive dims in [0,32)
-                const f32x4 c = *reinterpret_cast<const f32x4*>(p.cos + (size_t)t * 32 + d0);
-                const f32x4 s = *reinterpret_cast<const f32x4*>(p.sin + (size_t)t * 32 + d0);
+                const f32x4 c = *reinterpret_cast<const f32x4*>(p.cos + (size_t)t * rope_ld + sl * 32 + d0);
+                const f32x4 s = *reinterpret_cast<const f32x4*>(p.sin + (size_t)t * rope_ld + sl * 32 + d0);
                 float y1[4], y2[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -223,7 +231,7 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
                 const int mm = m_base + 32 * i + r;
                 if (FULL || mm < p.M) {
                     const int b = mm / p.T, tt = mm - b * p.T;
-                    *reinterpret_cast<V8*>(qk + ((size_t)(b * p.H + head) * p.T + tt) * 64 + cc * 8) = v[it];
+                    *reinterpret_cast<V8*>(qk + ((size_t)(b * p.H + head) * p.T + tt) * hd + sl * 64 + cc * 8) = v[it];
                 }
             }
         }
@@ -826,7 +834,8 @@ static hipError_t dispatch8(const GemmArgs& p, int epi, hipStream_t st) {
     if (mode == 1) return v1ref_launch(p, epi, std::is_same<T, _Float16>::value ? ESMK_DT_F16 : ESMK_DT_BF16, st);
     // generalised addressing requested?  (MSA Transformer calls, batched / strided / remapped GEMMs)
     const bool gen = p.a_row_bytes || p.w_row_bytes || p.a_kt_bytes || p.w_kt_bytes || p.batch > 1 || p.n_valid > 0 ||
-                     p.ldc > 0 || p.row_keep != nullptr || p.vt_rows > 0 || p.rowmap_R > 0 || epi == EPI_MSA_CTX;
+                     p.ldc > 0 || p.row_keep != nullptr || p.vt_rows > 0 || p.rowmap_R > 0 || epi == EPI_MSA_CTX ||
+                     p.head_dim != 64;
 #define ESMK_CASES(SC, DB, PFD)                                                          \
     switch (epi) {                                                                       \
         case EPI_STORE_T: return launch8<T, EPI_STORE_T, SC, DB, PFD>(p, st);            \

@@ -47,6 +47,7 @@ struct GemmArgs {
     int vt_rows = 0;                  // EPI_V_T: > 0 selects the layout [B,H,R = vt_rows,64,Tp], keys not permuted
     int rowmap_R = 0, rowmap_C = 0;   // EPI_RESID_F32: GEMM row (b,c,r) is added to output row (b,r,c)
     int ctx_R = 0, ctx_C = 0;         // EPI_MSA_CTX geometry
+    int head_dim = 64;                // EPI_QKV_ROPE / EPI_V_T: 64, or 128 (two 64-column slices per head)
 };
 
 hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st);
@@ -107,6 +108,13 @@ hipError_t launch_contacts(const float* attn, const int64_t* tokens, const float
 hipError_t launch_attention(const void* q, const void* k, const void* vt, const float* key_bias,
                             const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
                             int operand_dtype, hipStream_t st);
+// attention128.hip: head_dim 128 (esm2_t48_15B)
+hipError_t launch_attention128(const void* q, const void* k, const void* vt, const float* key_bias,
+                               const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
+                               int operand_dtype, hipStream_t st);
+hipError_t launch_attention_probs128(const void* q, const void* k, const float* lse, const float* key_bias,
+                                     float* probs, int B, int H, int T, int layer, int num_layers_total,
+                                     int operand_dtype, hipStream_t st);
 // same kernel, MSA column attention: key_fill[b,t] != 0 REPLACES the score by -10000 (masked_fill,
 // axial_attention.py:211-215) and is only applied when any_pad[0] != 0
 hipError_t launch_attention_fill(const void* q, const void* k, const void* vt, const float* key_fill,

@@ -170,6 +170,25 @@ def test_small_head_dims_against_oracle(name):
     assert cerr < 8e-3
 
 
+def test_head_dim_128_against_oracle():
+    """esm2_t48_15B geometry (head_dim 128) at reduced width / depth: 8 heads x 128, 2 layers, padded batch."""
+    L, E, H = 2, 1024, 8
+    model, sd = build(L, E, H, seed=19)
+    toks = synth_tokens(3, 300, seed=10)
+    toks[2, 200] = 2
+    toks[2, 201:] = 1
+    with torch.no_grad():
+        out = model(toks.cuda(), repr_layers=[0, 1, L], return_contacts=True)
+    ref = esm2_forward(sd, toks, L, H, repr_layers=[0, 1, L], return_contacts=True)
+    nonpad = toks.ne(1)
+    for l in (0, 1, L):
+        e = rel_err(out["representations"][l].cpu(), ref["representations"][l], nonpad)
+        assert e < REL_SMALL, (l, e)
+    assert rel_err(out["logits"].cpu(), ref["logits"], nonpad) < REL_SMALL
+    assert (out["attentions"].cpu() - ref["attentions"]).abs().max().item() < 4e-3
+    assert (out["contacts"].cpu() - ref["contacts"]).abs().max().item() < 8e-3
+
+
 def test_properties_full_length():
     """Size-independent properties at L=1022 with the 650M dimensions (no oracle needed):
     run-to-run determinism, batch-composition invariance (bit exact) and padding invariance."""
