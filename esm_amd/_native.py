@@ -31,6 +31,9 @@ class EsmkConfig(ctypes.Structure):
         ("prepend_bos", c_int32),
         ("append_eos", c_int32),
         ("operand_dtype", c_int32),
+        ("no_rope", c_int32),
+        ("num_positions", c_int32),
+        ("ln_before", c_int32),
     ]
 
 

@@ -7,8 +7,10 @@ Checkpoint formats understood
     token_dropout)}, "model": state}`` with the key prefixes ``encoder.sentence_encoder.`` /
     ``encoder.`` removed; dispatched by the file stem starting with ``esm2``;
   * optional sibling ``<stem>-contact-regression.pt`` holding ``contact_head.regression.*``.
-Other model families of the reference (ESM-1/1b/1v, MSA Transformer, ESM-IF1, ESMFold) are outside
-the MI355X engine's scope and raise ``NotImplementedError`` when a checkpoint asks for them.
+  * ``{"args": Namespace(arch=...), "model": state}``: ``msa_transformer`` (MSA Transformer) and
+    ``roberta_large`` (ESM-1b / ESM-1v), with the reference's key-prefix upgrades.
+Other model families of the reference (ESM-1 ``protein_bert_base``, ESM-IF1, ESMFold) are outside the MI355X
+engine's scope and raise ``NotImplementedError`` when a checkpoint asks for them.
 """
 import re
 import urllib
@@ -106,6 +108,10 @@ def _build_v1(model_data):
         from .msa_transformer import build_from_checkpoint
 
         return build_from_checkpoint(model_data)
+    if arch == "roberta_large":  # ESM-1b / ESM-1v
+        from .esm1 import build_from_checkpoint
+
+        return build_from_checkpoint(model_data)
     raise NotImplementedError(
         f"architecture {arch!r} is outside the scope of the MI355X ESM-2 engine "
         "(ESM-1 / ESM-1b / ESM-1v / ESM-IF1 are not implemented)"
@@ -157,6 +163,12 @@ _RELEASED = {
     "esm2_t33_650M_UR50D": "33 layer ESM-2 model with 650M params, trained on UniRef50.",
     "esm2_t36_3B_UR50D": "36 layer ESM-2 model with 3B params, trained on UniRef50.",
     "esm2_t48_15B_UR50D": "48 layer ESM-2 model with 15B params, trained on UniRef50.",
+    "esm1b_t33_650M_UR50S": "33 layer ESM-1b model with 650M params, trained on UniRef50.",
+    "esm1v_t33_650M_UR90S_1": "33 layer ESM-1v model with 650M params, trained on UniRef90 (ensemble member 1).",
+    "esm1v_t33_650M_UR90S_2": "33 layer ESM-1v model with 650M params, trained on UniRef90 (ensemble member 2).",
+    "esm1v_t33_650M_UR90S_3": "33 layer ESM-1v model with 650M params, trained on UniRef90 (ensemble member 3).",
+    "esm1v_t33_650M_UR90S_4": "33 layer ESM-1v model with 650M params, trained on UniRef90 (ensemble member 4).",
+    "esm1v_t33_650M_UR90S_5": "33 layer ESM-1v model with 650M params, trained on UniRef90 (ensemble member 5).",
     "esm_msa1_t12_100M_UR50S": "MSA Transformer (ESM-MSA-1), 12 layers, 100M params.",
     "esm_msa1b_t12_100M_UR50S": "MSA Transformer (ESM-MSA-1b), 12 layers, 100M params.",
 }

@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256) void seq_stats_kernel(const int64_t* __restric
                                                          int pad_idx, int mask_idx,
                                                          float* __restrict__ scale,
                                                          float* __restrict__ key_bias,
-                                                         int* __restrict__ seq_info) {
+                                                         int* __restrict__ seq_info,
+                                                         float* __restrict__ keep) {
     __shared__ int s_mask[4], s_pad[4], s_last[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int64_t* row = tokens + (size_t)b * T;
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(256) void seq_stats_kernel(const int64_t* __restric
         n_pad += is_pad;
         if (!is_pad) last = t + 1;
         key_bias[(size_t)b * T + t] = is_pad ? -INFINITY : 0.f;
+        if (keep != nullptr) keep[(size_t)b * T + t] = is_pad ? 0.f : 1.f;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -57,10 +59,81 @@ __global__ __launch_bounds__(256) void seq_stats_kernel(const int64_t* __restric
 
 hipError_t launch_seq_stats(const int64_t* tokens, int B, int T, int pad_idx, int mask_idx,
                             int token_dropout, float* scale, float* key_bias, int* seq_info,
-                            hipStream_t st) {
+                            hipStream_t st, float* keep) {
     (void)token_dropout;
     hipLaunchKernelGGL(seq_stats_kernel, dim3(B), dim3(256), 0, st, tokens, T, pad_idx, mask_idx,
-                       scale, key_bias, seq_info);
+                       scale, key_bias, seq_info, keep);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// learned positions of ESM-1b / ESM-1v — reference esm/model/esm1.py:133 and
+// LearnedPositionalEmbedding.forward (esm/modules.py:240-257):
+//   x[b,t,:] += embed_positions[cumsum(nonpad)[t] * nonpad[t] + pad_idx]         (one workgroup per sequence)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_positions_kernel(const int64_t* __restrict__ tokens,
+                                                             const float* __restrict__ pos_emb,
+                                                             float* __restrict__ x, int T, int E, int pad_idx,
+                                                             int npos) {
+    extern __shared__ int s_pos[];  // [T] position ids + 4 wave totals
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t* row = tokens + (size_t)b * T;
+    int* s_tot = s_pos + T;
+    int carry = 0;
+    for (int t0 = 0; t0 < T; t0 += 256) {
+        const int t = t0 + tid;
+        const int np = (t < T && row[t] != pad_idx) ? 1 : 0;
+        int v = np;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(v, o, 64);
+            if (lane >= o) v += u;
+        }
+        if (lane == 63) s_tot[wave] = v;
+        __syncthreads();
+        int base = carry;
+        for (int w = 0; w < wave; ++w) base += s_tot[w];
+        if (t < T) s_pos[t] = (v + base) * np + pad_idx;
+        carry += s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+        __syncthreads();
+    }
+    const int e4 = E >> 2;
+    for (int idx = tid; idx < T * e4; idx += 256) {
+        const int t = idx / e4, k = idx - t * e4;
+        const int ps = min(s_pos[t], npos - 1);
+        const f32x4 pe = reinterpret_cast<const f32x4*>(pos_emb + (size_t)ps * E)[k];
+        f32x4* dst = reinterpret_cast<f32x4*>(x + ((size_t)b * T + t) * E) + k;
+        f32x4 v = *dst;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += pe[e];
+        *dst = v;
+    }
+}
+
+hipError_t launch_add_positions(const int64_t* tokens, const float* pos_emb, float* x, int B, int T, int E,
+                                int pad_idx, int npos, hipStream_t st) {
+    if (E % 4 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(add_positions_kernel, dim3(B), dim3(256), (size_t)(T + 4) * sizeof(int), st, tokens, pos_emb,
+                       x, T, E, pad_idx, npos);
+    return hipGetLastError();
+}
+
+// rows of x multiplied by keep[row] (esm1.py:138-139 when there is no emb_layer_norm_before to fold it into)
+__global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ x, const float* __restrict__ keep,
+                                                          size_t n4, int e4) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float kp = keep[i / e4];
+    f32x4 v = reinterpret_cast<f32x4*>(x)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= kp;
+    reinterpret_cast<f32x4*>(x)[i] = v;
+}
+
+hipError_t launch_scale_rows(float* x, const float* keep, int rows, int E, hipStream_t st) {
+    const size_t n4 = (size_t)rows * (E / 4);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, keep, n4, E / 4);
     return hipGetLastError();
 }
 

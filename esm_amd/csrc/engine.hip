@@ -111,6 +111,11 @@ void plan_packed(esmk_model* m) {
     m->lm_bias = c.take(V * 4);
     m->ct_w = c.take((size_t)m->L * m->H * 4);
     m->ct_b = c.take(4);
+    if (m->cfg.num_positions > 0) m->pos_emb = c.take((size_t)m->cfg.num_positions * E * 4);
+    if (m->cfg.ln_before) {
+        m->lnb_g = c.take(E * 4);
+        m->lnb_b = c.take(E * 4);
+    }
     m->layer.resize(m->L);
     for (int l = 0; l < m->L; ++l) {
         LayerOff& o = m->layer[l];
@@ -173,7 +178,7 @@ void plan_packed_msa(esmk_model* m) {
 }
 
 struct Workspace {
-    size_t scale, key_bias, seq_info, x, h, big, lse, ct_scratch, total;
+    size_t scale, key_bias, seq_info, keep, x, h, big, lse, ct_scratch, total;
     size_t q, k, vt;  // inside big
     int Tp;
 };
@@ -187,6 +192,7 @@ Workspace plan_workspace(const esmk_model* m, int B, int T, uint32_t flags) {
     w.scale = c.take(B * 4);
     w.key_bias = c.take(N * 4);
     w.seq_info = c.take((size_t)B * 2 * 4);
+    w.keep = c.take(m->cfg.num_positions > 0 ? N * 4 : 0);
     w.x = c.take(N * E * 4);
     w.h = c.take(N * std::max(Kp, EA) * os);
     const size_t qb = align_up(N * EA * os);
@@ -243,7 +249,7 @@ int ensure_unit_rope(esmk_model* m, int T, hipStream_t st) {
         m->d_ucos = m->d_usin = nullptr;
         m->unit_cap = 0;
     }
-    const size_t n = (size_t)cap * 32;
+    const size_t n = (size_t)cap * 64;  // row stride 32 (head_dim <= 64) or 64 (head_dim 128)
     ESMK_TRY(hipMalloc(&m->d_ucos, n * 4));
     ESMK_TRY(hipMalloc(&m->d_usin, n * 4));
     hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->d_ucos, 1.0f, n);
@@ -432,6 +438,10 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
         }
     }
     if (!strcmp(key, "lm_head.weight")) return 0;  // tied to embed_tokens.weight (esm2.py:71-75)
+    if (!m->is_msa && m->cfg.num_positions > 0 && !strcmp(key, "embed_positions.weight"))
+        return put(m->pos_emb, ESMK_DT_F32, (size_t)m->cfg.num_positions * E);
+    if (!m->is_msa && m->cfg.ln_before && !strcmp(key, "emb_layer_norm_before.weight")) return put(m->lnb_g, ESMK_DT_F32, E);
+    if (!m->is_msa && m->cfg.ln_before && !strcmp(key, "emb_layer_norm_before.bias")) return put(m->lnb_b, ESMK_DT_F32, E);
     if (!strcmp(key, "emb_layer_norm_after.weight")) return put(m->fin_g, ESMK_DT_F32, E);
     if (!strcmp(key, "emb_layer_norm_after.bias")) return put(m->fin_b, ESMK_DT_F32, E);
     if (!strcmp(key, "lm_head.dense.weight")) return put2d(m->lm_w, op, E, E, Kp, 0, 0);
@@ -517,7 +527,11 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
     float* g32 = (float*)(ws + w.big);
     float* lse = want_attn ? (float*)(ws + w.lse) : nullptr;
 
-    if (ensure_rope(m, T, st)) return 1;
+    if (m->cfg.no_rope) {
+        if (ensure_unit_rope(m, T, st)) return 1;
+    } else if (ensure_rope(m, T, st)) {
+        return 1;
+    }
 
     const double NE = (double)N * E;
     auto repr_copy = [&](int layer, const float* src) -> int {
@@ -554,10 +568,27 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
     // esm2.py:82-95
     {
         ProfScope ps(m, st, PC_EMBED, 0, (double)N * 8 + 4 * NE);
+        const bool esm1b = m->cfg.num_positions > 0;
+        float* keep = esm1b ? (float*)(ws + w.keep) : nullptr;
         ESMK_TRY(launch_seq_stats(tokens_dev, B, T, m->cfg.pad_idx, m->cfg.mask_idx,
-                                  m->cfg.token_dropout, scale, key_bias, seq_info, st));
+                                  m->cfg.token_dropout, scale, key_bias, seq_info, st, keep));
         ESMK_TRY(launch_embed(tokens_dev, (const float*)(pk + m->embed_f32), scale, x, B, T, E, m->V,
                               m->cfg.pad_idx, m->cfg.mask_idx, m->cfg.token_dropout, st));
+        if (esm1b) {
+            // esm1.py:133-139: + learned positions, emb_layer_norm_before, padded positions zeroed
+            if (T > m->cfg.num_positions - m->cfg.pad_idx - 1)
+                return fail("esmk_forward: sequence length above the maximum of the positional embedding");
+            ESMK_TRY(launch_add_positions(tokens_dev, (const float*)(pk + m->pos_emb), x, B, T, E, m->cfg.pad_idx,
+                                          m->cfg.num_positions, st));
+            if (m->cfg.ln_before) {
+                LnExtra ex;
+                ex.row_keep = keep;
+                ESMK_TRY(launch_layernorm_ex(x, (const float*)(pk + m->lnb_g), (const float*)(pk + m->lnb_b), nullptr,
+                                             x, N, E, op, ex, st));
+            } else {
+                ESMK_TRY(launch_scale_rows(x, keep, N, E, st));
+            }
+        }
     }
     if (repr_copy(0, x)) return 1;  // esm2.py:99-100
 
@@ -578,8 +609,8 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.q = q;
         g.k = k;
         g.vt = vt;
-        g.cos = m->d_cos;
-        g.sin = m->d_sin;
+        g.cos = m->cfg.no_rope ? m->d_ucos : m->d_cos;
+        g.sin = m->cfg.no_rope ? m->d_usin : m->d_sin;
         g.T = T;
         g.H = H;
         g.E = EA;

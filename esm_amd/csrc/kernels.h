@@ -63,7 +63,11 @@ void gemm8_set_timing(unsigned long long* dev_buf);
 // seq_info[2b+1] = 1 + index of the last non-pad token
 hipError_t launch_seq_stats(const int64_t* tokens, int B, int T, int pad_idx, int mask_idx,
                             int token_dropout, float* scale, float* key_bias, int* seq_info,
-                            hipStream_t st);
+                            hipStream_t st, float* keep = nullptr);  // keep[b,t] = 1 - pad (optional)
+// ESM-1b / ESM-1v: x += embed_positions[...] (esm1.py:133, modules.py:240-257); x *= keep (esm1.py:138-139)
+hipError_t launch_add_positions(const int64_t* tokens, const float* pos_emb, float* x, int B, int T, int E,
+                                int pad_idx, int npos, hipStream_t st);
+hipError_t launch_scale_rows(float* x, const float* keep, int rows, int E, hipStream_t st);
 // embedding gather + token-dropout rescale + pad zeroing (esm2.py:84-95)
 hipError_t launch_embed(const int64_t* tokens, const float* table, const float* scale, float* x,
                         int B, int T, int E, int vocab, int pad_idx, int mask_idx,

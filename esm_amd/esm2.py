@@ -99,19 +99,24 @@ class _Engine:
         self.N = N
         self.device = device
         self.operand_dtype = operand_dtype
+        # ESM-1b / ESM-1v (esm_amd.esm1.ProteinBertModel) set these; ESM-2 leaves them at zero
+        self.no_rope = int(getattr(model, "_engine_no_rope", 0))
+        num_positions = int(getattr(model, "_engine_num_positions", 0))
+        ln_before = int(getattr(model, "_engine_ln_before", 0))
         cfg = N.EsmkConfig(
-            model.num_layers, model.embed_dim, model.attention_heads, 4 * model.embed_dim,
+            model.num_layers, model.embed_dim, model.attention_heads, int(getattr(model, "ffn_embed_dim", 4 * model.embed_dim)),
             model.alphabet_size, model.padding_idx, model.mask_idx, model.cls_idx, model.eos_idx,
             int(bool(model.token_dropout)), int(bool(model.prepend_bos)), int(bool(model.append_eos)),
-            N.dtype_code(operand_dtype),
+            N.dtype_code(operand_dtype), self.no_rope, num_positions, ln_before,
         )
         self.handle = ctypes.c_void_p()
         with torch.cuda.device(device):
             N.check(N.lib.esmk_create(ctypes.byref(cfg), ctypes.byref(self.handle)))
-            d = model.embed_dim // model.attention_heads
-            inv = (1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))).tolist()
-            arr = (ctypes.c_float * len(inv))(*inv)
-            N.check(N.lib.esmk_set_rope_inv_freq(self.handle, arr, len(inv)))
+            if not self.no_rope:
+                d = model.embed_dim // model.attention_heads
+                inv = (1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))).tolist()
+                arr = (ctypes.c_float * len(inv))(*inv)
+                N.check(N.lib.esmk_set_rope_inv_freq(self.handle, arr, len(inv)))
             nbytes = ctypes.c_size_t()
             N.check(N.lib.esmk_packed_bytes(self.handle, ctypes.byref(nbytes)))
             # zero-initialised: padded head slots / K columns of the packed image must stay zero

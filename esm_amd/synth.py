@@ -195,3 +195,30 @@ def synth_msa_tokens(batch, rows, cols, seed=1, gap_frac=0.05, device="cpu"):
     toks[gaps] = 30
     toks[:, :, 0] = 0
     return toks.to(device)
+
+
+# ---------------------------------------------------------------------------------------------------
+# ESM-1b / ESM-1v (reference esm/model/esm1.py, arch "roberta_large")
+# ---------------------------------------------------------------------------------------------------
+def synth_esm1b_state_dict(num_layers, embed_dim, heads, ffn_dim=None, seed=0, qk_gain=2.0, max_positions=1024,
+                           ln_before=True):
+    """fp32 ESM-1b state dict with the reference's key names: the ESM-2 keys without rot_emb.inv_freq, plus
+    embed_positions.weight and (optionally) emb_layer_norm_before.*."""
+    ffn_dim = ffn_dim or 4 * embed_dim
+    sd = {k: v for k, v in synth_esm2_state_dict(num_layers, embed_dim, heads, seed=seed, qk_gain=qk_gain).items()
+          if not k.endswith("inv_freq")}
+    if ffn_dim != 4 * embed_dim:
+        for i in range(num_layers):
+            for key, shape in ((f"layers.{i}.fc1.weight", (ffn_dim, embed_dim)), (f"layers.{i}.fc1.bias", (ffn_dim,)),
+                               (f"layers.{i}.fc2.weight", (embed_dim, ffn_dim))):
+                std = 0.02 * (1280.0 / shape[1]) ** 0.5 if len(shape) == 2 else 0.02
+                sd[key] = _draw(key, shape, seed, std)
+    sd["embed_positions.weight"] = _draw("embed_positions.weight", (max_positions + 2, embed_dim), seed, 0.1)
+    sd["embed_positions.weight"][1] = 0.0
+    if ln_before:
+        sd["emb_layer_norm_before.weight"] = _draw("emb_layer_norm_before.weight", (embed_dim,), seed, 0.02, mean=1.0)
+        sd["emb_layer_norm_before.bias"] = _draw("emb_layer_norm_before.bias", (embed_dim,), seed, 0.02)
+    sd["embed_tokens.weight"] = sd["embed_tokens.weight"].clone()
+    sd["embed_tokens.weight"][32] = 0.0  # pretrained.py:97 zeroes the <mask> row for token dropout
+    sd["lm_head.weight"] = sd["embed_tokens.weight"]
+    return sd

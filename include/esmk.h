@@ -51,6 +51,12 @@ typedef struct esmk_config {
     int32_t prepend_bos, append_eos; /* contact head crop (modules.py:338-347)           */
     int32_t operand_dtype;   /* ESMK_F16 or ESMK_BF16: MFMA operand type; accumulation,
                                 residual stream, LayerNorm, softmax are always fp32     */
+    /* ESM-1b / ESM-1v (ProteinBertModel with arch "roberta_large", esm/model/esm1.py:88-104,117-143); all
+     * zero for ESM-2 */
+    int32_t no_rope;         /* 1: no rotary embedding (TransformerLayer(use_rotary_embeddings=False)) */
+    int32_t num_positions;   /* > 0: rows of the LearnedPositionalEmbedding table added to the token embedding
+                                (esm1.py:133, modules.py:240-257); key "embed_positions.weight"   */
+    int32_t ln_before;       /* 1: emb_layer_norm_before (esm1.py:136-137)                          */
 } esmk_config;
 
 const char* esmk_last_error(void);

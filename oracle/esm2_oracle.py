@@ -46,7 +46,7 @@ def apply_rope(x, cos, sin):
     return x * cos + rot * sin
 
 
-def attention_layer(sd, prefix, x, heads, pad_mask, need_weights):
+def attention_layer(sd, prefix, x, heads, pad_mask, need_weights, use_rope=True):
     """Self-attention of one TransformerLayer on x [B,T,E] (reference works on [T,B,E], the math
     is layout independent).  reference esm/multihead_attention.py:256-261 (projections, q scaling),
     :280-284 (head split), :354-355 (rotary), :357 (scores), :368-374 (key padding -inf),
@@ -58,8 +58,9 @@ def attention_layer(sd, prefix, x, heads, pad_mask, need_weights):
     k = F.linear(x, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"])
     v = F.linear(x, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"])
     q, k, v = (t.view(B, T, heads, d).transpose(1, 2) for t in (q, k, v))  # [B,H,T,d]
-    cos, sin = rope_tables(T, d, x.device)
-    q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
+    if use_rope:  # ESM-2 (TransformerLayer(use_rotary_embeddings=True), esm2.py:57-66); ESM-1b has none
+        cos, sin = rope_tables(T, d, x.device)
+        q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
     scores = q @ k.transpose(-1, -2)  # [B,H,T,T]
     if pad_mask is not None:
         scores = scores.masked_fill(pad_mask[:, None, None, :], float("-inf"))
@@ -69,11 +70,11 @@ def attention_layer(sd, prefix, x, heads, pad_mask, need_weights):
     return out, (probs if need_weights else None)
 
 
-def transformer_layer(sd, i, x, heads, pad_mask, need_weights):
+def transformer_layer(sd, i, x, heads, pad_mask, need_weights, use_rope=True):
     # reference esm/modules.py:120-142 (pre-LN residual blocks)
     p = f"layers.{i}."
     h = layer_norm(x, sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"])
-    a, probs = attention_layer(sd, p, h, heads, pad_mask, need_weights)
+    a, probs = attention_layer(sd, p, h, heads, pad_mask, need_weights, use_rope)
     x = x + a
     h = layer_norm(x, sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"])
     h = gelu(F.linear(h, sd[p + "fc1.weight"], sd[p + "fc1.bias"]))

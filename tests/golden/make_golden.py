@@ -146,7 +146,56 @@ def main_msa():
         print(name, "->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+ESM1B_CASES = {
+    "tiny_d64": dict(L=2, E=128, H=2, seed=31, T=21, B=3, ln_before=True),
+    "nolnb_d64": dict(L=2, E=192, H=3, seed=32, T=40, B=2, ln_before=False),
+}
+
+
+def main_esm1b():
+    import argparse
+
+    sys.path.insert(0, ROOT)
+    from esm_amd.synth import synth_esm1b_state_dict
+
+    sys.path.insert(0, REFERENCE)
+    for k in [k for k in sys.modules if k == "esm" or k.startswith("esm.")]:
+        del sys.modules[k]
+    ref = importlib.import_module("esm")
+    assert ref.__file__.startswith(REFERENCE), ref.__file__
+    alphabet = ref.Alphabet.from_architecture("roberta_large")
+    for name, c in ESM1B_CASES.items():
+        sd = synth_esm1b_state_dict(c["L"], c["E"], c["H"], seed=c["seed"], ln_before=c["ln_before"])
+        args = argparse.Namespace(arch="roberta_large", layers=c["L"], embed_dim=c["E"], ffn_embed_dim=4 * c["E"],
+                                  attention_heads=c["H"], max_positions=1024, token_dropout=True,
+                                  emb_layer_norm_before=c["ln_before"])
+        model = ref.ProteinBertModel(args, alphabet).eval()
+        model.load_state_dict(sd, strict=True)
+        toks = build_tokens(c["B"], c["T"], c["seed"])
+        with torch.no_grad():
+            out = model(toks, repr_layers=list(range(c["L"] + 1)), return_contacts=True)
+        fix = {
+            "dims": {k: c[k] for k in ("L", "E", "H", "seed", "ln_before")},
+            "tokens": toks,
+            "weights_checksum": float(sum(v.double().sum() for k, v in sd.items() if k != "lm_head.weight")),
+            "logits": out["logits"].float(),
+            "representations": {k: v.float() for k, v in out["representations"].items()},
+            "attentions": out["attentions"].float(),
+            "contacts": out["contacts"].float(),
+            "reference_version": getattr(ref, "__version__", "?"),
+            "torch_version": torch.__version__,
+        }
+        path = os.path.join(HERE, f"esm1b_{name}.pt")
+        torch.save(fix, path)
+        print(name, "->", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    if "--msa-only" not in sys.argv:
+    if "--msa-only" in sys.argv:
+        main_msa()
+    elif "--esm1b-only" in sys.argv:
+        main_esm1b()
+    else:
         main()
-    main_msa()
+        main_msa()
+        main_esm1b()
