@@ -296,6 +296,231 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
         lse[(size_t)bh * Tlen + qrow] = m2 * (1.0f / LOG2E) + logf(ltot);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// attn_fwd2_kernel: same algorithm, 64 query rows per wave (two independent 32-row blocks), 256 per
+// workgroup.  Every K / V^T fragment read from the LDS feeds two MFMAs, and the two blocks' softmax
+// chains are independent instruction streams inside one wave: while block 0's exponentials occupy the
+// VALU, block 1's MFMAs (and vice versa) keep the matrix pipe busy without relying on another workgroup
+// being in the complementary phase.  ~230 VGPRs -> 2 waves per SIMD.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(
+    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
+    const float* __restrict__ key_bias, const int* __restrict__ seq_info, T* __restrict__ ctx,
+    float* __restrict__ lse, int H, int BH, int nq, int Tlen, int Tp, int fill_mode,
+    const int* __restrict__ any_pad) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * A_STAGE];
+    using V8 = typename Op<T>::v8;
+    using V4 = typename Op<T>::v4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, lm = lane & 31;
+    int bh, qblk;
+    {
+        const int id = blockIdx.x;
+        const int bh8 = BH & ~7;
+        if (id < bh8 * nq) {
+            const int r = id >> 3;
+            qblk = r % nq;
+            bh = (r / nq) * 8 + (id & 7);
+        } else {
+            const int r = id - bh8 * nq;
+            bh = bh8 + r / nq;
+            qblk = r % nq;
+        }
+    }
+    const int b = bh / H, head = bh - b * H;
+    const int q0 = qblk * 256 + wave * 64;  // block 0: rows q0..q0+31, block 1: q0+32..q0+63
+
+    int kv_end = Tlen;
+    bool use_mask = (Tlen & 63) != 0;
+    if (fill_mode) {
+        if (key_bias != nullptr && any_pad != nullptr && any_pad[0] != 0) use_mask = true;
+        else key_bias = nullptr;
+    } else if (key_bias != nullptr) {
+        if (seq_info != nullptr) {
+            if (seq_info[2 * b] > 0) {
+                use_mask = true;
+                kv_end = seq_info[2 * b + 1];
+            }
+        } else {
+            use_mask = true;
+        }
+    }
+    const int ntiles = (kv_end + 63) >> 6;
+    const T* kb = k + (size_t)bh * Tlen * 64;
+    const T* vb = vt + (size_t)bh * 64 * Tp;
+
+    V8 qf[2][4];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int qr = min(q0 + 32 * blk + lm, Tlen - 1);
+        const T* qp = q + ((size_t)bh * Tlen + qr) * 64 + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[blk][ks] = *reinterpret_cast<const V8*>(qp + 16 * ks);
+    }
+
+    const T* gk[2];
+    const T* gv[2];
+    int krow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pos = j * 256 + tid;
+        const int r = pos >> 3, sl = pos & 7;
+        const int c = sl ^ ((r >> 1) & 7);
+        krow[j] = r;
+        gk[j] = kb + c * 8;
+        gv[j] = vb + (size_t)r * Tp + c * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * A_STAGE;
+        const int k0 = kt * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kr = min(k0 + krow[j], Tlen - 1);
+            glds16(gk[j] + (size_t)kr * 64, base + (j * 256 + wave * 64) * 16);
+            glds16(gv[j] + k0, base + A_TILE + (j * 256 + wave * 64) * 16);
+        }
+        if (use_mask && tid < 64) {
+            const int key = k0 + tid;
+            float bv = -INFINITY;
+            if (key < Tlen) {
+                bv = key_bias ? key_bias[(size_t)b * Tlen + key] : 0.f;
+                if (fill_mode) bv = (bv != 0.f) ? INFINITY : 0.f;
+            }
+            reinterpret_cast<float*>(base + 2 * A_TILE)[tid] = bv;
+        }
+    };
+
+    const int lrow = lm * 128;
+    const int swz = (lane >> 1) & 7;
+    int xo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xo[c] = ((2 * c + h) ^ swz) << 4;
+
+    f32x16 o[2][2];
+    float m2[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[blk][d][r] = 0.f;
+
+    if (ntiles > 0) stage(0, 0);
+    wait_vmcnt0();
+    __syncthreads();
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < ntiles) stage(cur ^ 1, kt + 1);
+        const char* sk = smem + cur * A_STAGE;
+        const char* sv = sk + A_TILE;
+        const float* sb = reinterpret_cast<const float*>(sk + 2 * A_TILE);
+
+        // ---- S^T = K . Q^T: every K fragment serves both query blocks ---------------------------------
+        f32x16 st[2][2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[blk][t2][r] = 0.f;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const V8 kf = *reinterpret_cast<const V8*>(sk + t2 * 4096 + lrow + xo[ks]);
+                st[0][t2] = Op<T>::mma(kf, qf[0][ks], st[0][t2]);
+                st[1][t2] = Op<T>::mma(kf, qf[1][ks], st[1][t2]);
+            }
+        if (use_mask) {
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(sb + t2 * 32 + 8 * g + 4 * h);
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            st[blk][t2][4 * g + e] = (bv[e] == INFINITY) ? -10000.f : st[blk][t2][4 * g + e] + bv[e];
+                }
+        }
+        // ---- online softmax, two independent chains ---------------------------------------------------------
+        V8 pf[2][4];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            float mx = st[blk][0][0];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[blk][t2][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m2[blk], mx * LOG2E);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m2[blk] - m_use);
+            m2[blk] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float pv = __builtin_amdgcn_exp2f(st[blk][t2][8 * ks + e] * LOG2E - m_use);
+                        ps += pv;
+                        pf[blk][2 * t2 + ks][e] = Op<T>::from(pv);
+                    }
+            lsum[blk] = lsum[blk] * alpha + ps;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[blk][d][r] *= alpha;
+        }
+        // ---- O^T += V^T . P^T: every V^T fragment serves both query blocks ---------------------------------
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const V8 vf = *reinterpret_cast<const V8*>(sv + d * 4096 + lrow + xo[kk]);
+                o[0][d] = Op<T>::mma(vf, pf[0][kk], o[0][d]);
+                o[1][d] = Op<T>::mma(vf, pf[1][kk], o[1][d]);
+            }
+        wait_vmcnt0();
+        __syncthreads();
+    }
+
+    // ---- normalise and store: [64 queries][64 dv] per wave through an 8 KiB LDS slice ----------------------
+    char* wl = smem + wave * 8192;
+    T* dst = ctx + ((size_t)b * Tlen) * ((size_t)H * 64) + head * 64;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const float ltot = lsum[blk] + __shfl_xor(lsum[blk], 32, 64);
+        const float inv = 1.0f / ltot;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                V4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = Op<T>::from(o[blk][d][4 * g + e] * inv);
+                *reinterpret_cast<V4*>(wl + (32 * blk + lm) * 128 + (((4 * d + g) ^ (lm & 7)) << 4) + 8 * h) = pk;
+            }
+        const int qrow = q0 + 32 * blk + lm;
+        if (lse != nullptr && h == 0 && qrow < Tlen)
+            lse[(size_t)bh * Tlen + qrow] = m2[blk] * (1.0f / LOG2E) + logf(ltot);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int pc = it * 64 + lane;
+        const int r = pc >> 3, c = pc & 7;
+        const V8 v = *reinterpret_cast<const V8*>(wl + r * 128 + ((c ^ (r & 7)) << 4));
+        if (q0 + r < Tlen) *reinterpret_cast<V8*>(dst + (size_t)(q0 + r) * ((size_t)H * 64) + c * 8) = v;
+    }
+}
+
 static hipError_t launch_attention_impl(const void* q, const void* k, const void* vt, const float* key_bias,
                                         const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
                                         int operand_dtype, int fill_mode, const int* any_pad, hipStream_t st);
@@ -333,7 +558,18 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
         case 2: ESMK_ATTN_LAUNCH(TT, 2, 1); break;               \
         default: ESMK_ATTN_LAUNCH(TT, 3, 1); break;              \
     }
-    if (operand_dtype == ESMK_DT_BF16) {
+    if (var & 8) {  // 64 query rows per wave
+        const int nq2 = (T + 255) / 256;
+        dim3 grid2(nq2 * B * H);
+        if (operand_dtype == ESMK_DT_BF16)
+            hipLaunchKernelGGL((attn_fwd2_kernel<__bf16>), grid2, dim3(256), 0, st, (const __bf16*)q, (const __bf16*)k,
+                               (const __bf16*)vt, key_bias, seq_info, (__bf16*)ctx, lse, H, B * H, nq2, T, Tp, fill_mode,
+                               any_pad);
+        else
+            hipLaunchKernelGGL((attn_fwd2_kernel<_Float16>), grid2, dim3(256), 0, st, (const _Float16*)q,
+                               (const _Float16*)k, (const _Float16*)vt, key_bias, seq_info, (_Float16*)ctx, lse, H, B * H,
+                               nq2, T, Tp, fill_mode, any_pad);
+    } else if (operand_dtype == ESMK_DT_BF16) {
         ESMK_ATTN_VARIANTS(__bf16)
     } else {
         ESMK_ATTN_VARIANTS(_Float16)

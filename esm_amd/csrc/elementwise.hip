@@ -5,6 +5,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace esmk {
 
@@ -317,6 +318,7 @@ static hipError_t ln_dispatch(const float* x, const float* g, const float* b, vo
         case 1: return ln_dispatch_v<T, 1>(x, g, b, y, y32, rows, E, ex, st);
         case 2: return ln_dispatch_v<T, 2>(x, g, b, y, y32, rows, E, ex, st);
         case 3: return ln_dispatch_v<T, 3>(x, g, b, y, y32, rows, E, ex, st);
+        case 5: return ln_dispatch_v<T, 5>(x, g, b, y, y32, rows, E, ex, st);
         case 6: return ln_dispatch_v<T, 6>(x, g, b, y, y32, rows, E, ex, st);
         case 7: return ln_dispatch_v<T, 7>(x, g, b, y, y32, rows, E, ex, st);
     }
@@ -333,8 +335,12 @@ hipError_t launch_layernorm_ex(const float* x, const float* gamma, const float* 
                                hipStream_t st) {
     if (E % 4 != 0 || rows <= 0) return hipErrorInvalidValue;
     // bits 8..11 of operand_dtype: kernel variant + 1 (micro-benchmarks); 0 = engine default
+    static const int env_variant = [] {
+        const char* e = getenv("ESMK_LN");
+        return e ? atoi(e) : LN_DEFAULT_VARIANT;
+    }();
     const int vsel = (operand_dtype >> 8) & 0xf;
-    const int variant = vsel ? vsel - 1 : LN_DEFAULT_VARIANT;
+    const int variant = vsel ? vsel - 1 : env_variant;
     operand_dtype &= 0xff;
     if (operand_dtype == ESMK_DT_BF16)
         return ln_dispatch<__bf16>(x, gamma, beta, y, y32, rows, E, variant, ex, st);

@@ -786,18 +786,8 @@ static hipError_t launch8(GemmArgs p, hipStream_t st) {
     return hipGetLastError();
 }
 
-namespace v1ref {
-hipError_t launch_gemm8_v1(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st);
-}
-static hipError_t v1ref_launch(const GemmArgs& p, int epi, int dt, hipStream_t st) {
-    GemmArgs q = p;
-    q.dbg = 0;
-    return v1ref::launch_gemm8_v1(q, epi, dt, st);
-}
-
 template <typename T>
 static hipError_t dispatch8(const GemmArgs& p, int epi, hipStream_t st) {
-    if (p.dbg == 0xff) return v1ref_launch(p, epi, std::is_same<T, _Float16>::value ? ESMK_DT_F16 : ESMK_DT_BF16, st);
     if (p.dbg) {  // timing experiments and schedule A/B (tools/microbench.py)
         if constexpr (std::is_same<T, _Float16>::value) {
             if (epi == EPI_STORE_T) {
@@ -825,13 +815,11 @@ static hipError_t dispatch8(const GemmArgs& p, int epi, hipStream_t st) {
     static const int mode = [] {
         const char* e = getenv("ESMK_GEMM8_MODE");
         if (e == nullptr) return 0;
-        if (!strcmp(e, "v1")) return 1;
         if (!strcmp(e, "pf4")) return 2;
         if (!strcmp(e, "young")) return 3;
         if (!strcmp(e, "noxpf")) return 4;
         return 0;
     }();
-    if (mode == 1) return v1ref_launch(p, epi, std::is_same<T, _Float16>::value ? ESMK_DT_F16 : ESMK_DT_BF16, st);
     // generalised addressing requested?  (MSA Transformer calls, batched / strided / remapped GEMMs)
     const bool gen = p.a_row_bytes || p.w_row_bytes || p.a_kt_bytes || p.w_kt_bytes || p.batch > 1 || p.n_valid > 0 ||
                      p.ldc > 0 || p.row_keep != nullptr || p.vt_rows > 0 || p.rowmap_R > 0 || epi == EPI_MSA_CTX ||

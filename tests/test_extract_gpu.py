@@ -1,0 +1,50 @@
+"""The sharded extraction driver (python -m esm_amd.extract, the repo's mirror of the reference's
+scripts/extract.py) end to end on one MI355X: synthetic checkpoint + FASTA -> per-sequence .pt files and the
+gathered mean-embedding matrix, checked against the oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from esm_amd.synth import synth_esm2_state_dict, write_esm2_checkpoint
+from oracle.esm2_oracle import esm2_forward
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_extract_cli_matches_oracle(tmp_path):
+    L, E, H = 3, 320, 20  # esm2_t6_8M width (head_dim 16), 3 layers
+    ckpt = write_esm2_checkpoint(str(tmp_path), "esm2_synth_8M", L, E, H, seed=5)
+    g = torch.Generator().manual_seed(3)
+    aas = "LAGVSERTIDPKQNFYMHWC"
+    seqs = {f"prot{i}": "".join(aas[j] for j in torch.randint(0, 20, (n,), generator=g).tolist())
+            for i, n in enumerate([57, 130, 33, 250, 91])}
+    fasta = tmp_path / "in.fasta"
+    fasta.write_text("".join(f">{k}\n{v}\n" for k, v in seqs.items()))
+    out_dir = tmp_path / "out"
+    env = dict(os.environ, PYTHONPATH=ROOT, TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD="1")
+    subprocess.run([sys.executable, "-m", "esm_amd.extract", ckpt, str(fasta), str(out_dir), "--repr_layers", "-1", "0",
+                    "--include", "mean", "per_tok", "bos", "--toks_per_batch", "300", "--mean_matrix",
+                    str(tmp_path / "means.pt")], check=True, env=env, cwd=ROOT, timeout=600)
+    sd = synth_esm2_state_dict(L, E, H, seed=5)
+    from esm_amd import Alphabet
+
+    alphabet = Alphabet.from_architecture("ESM-1b")
+    means = torch.load(tmp_path / "means.pt", weights_only=False)
+    assert means["labels"] == list(seqs)
+    for i, (label, s) in enumerate(seqs.items()):
+        toks = torch.tensor([[alphabet.cls_idx] + alphabet.encode(s) + [alphabet.eos_idx]])
+        ref = esm2_forward(sd, toks, L, H, repr_layers=[0, L])
+        r = torch.load(out_dir / f"{label}.pt", weights_only=False)
+        assert r["label"] == label and sorted(r["representations"]) == [0, L]
+        for l in (0, L):
+            want = ref["representations"][l][0, 1:len(s) + 1]
+            got = r["representations"][l]
+            assert got.shape == want.shape
+            assert (got - want).abs().max().item() < 2e-3 * want.abs().max().item() + 1e-6
+            assert (r["mean_representations"][l] - want.mean(0)).abs().max().item() < 2e-3
+            assert (r["bos_representations"][l] - ref["representations"][l][0, 0]).abs().max().item() < 2e-3 * want.abs().max().item() + 1e-6
+        assert (means["mean_representations"][L][i] - ref["representations"][L][0, 1:len(s) + 1].mean(0)).abs().max().item() < 2e-3

@@ -66,26 +66,25 @@ def main():
         for name, N, K in [("fc2 shape", E, F), ("fc1 shape", F, E)]:
             a = rnd(M, K).to(dt); w = (rnd(N, K) / math.sqrt(K)).to(dt); bias = rnd(N)
             ntiles, nk = (M // 256) * (N // 256) // 256, K // 64
-            for dbg, what in [(0, "full"), (0xff, "v1 reference (commit d2404fb)"), (0x82, "L2 prefetch +2"), (0x83, "L2 prefetch +3"),
-                              (0x84, "L2 prefetch +4"), (0x86, "L2 prefetch +6"), (0x60, "DMA re-reads K slab 0"), (0x08, "no epilogue"),
-                              (0x8c, "prefetch +4, no epilogue"), (0x68, "slab 0, no epilogue"), (0x20, "epilogue w/o global stores"),
+            for dbg, what in [(0, "full"), (0x60, "DMA re-reads K slab 0"), (0x08, "no epilogue"),
+                              (0x68, "slab 0, no epilogue"), (0x20, "epilogue w/o global stores"),
                               (0x40, "young stores in flight"), (0x01, "no MFMA"), (0x02, "no LDS-DMA"), (0x04, "no fragment reads"),
                               (0x06, "no DMA, no reads"), (0x0e, "MFMA + barriers only")]:
                 fn = lambda: ops.linear(a, w, bias, nat.EPI_STORE_T, dbg=dbg)
                 ms = timeit(fn, args.iters)
-                extra = stamps(fn, ntiles, nk) if dbg in (0, 0x84, 0x60, 0x08, 0x0e) else ""
+                extra = stamps(fn, ntiles, nk) if dbg in (0, 0x60, 0x08, 0x0e) else ""
                 print(f"gemm8 {name} dbg={dbg:#04x} ({what:30s}): {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TFLOP/s  {extra}", flush=True)
             del a, w
         for name, N, K, epi in [("fc1 gelu", F, E, nat.EPI_GELU_T), ("fc2 resid", E, F, nat.EPI_RESID_F32), ("out resid", E, E, nat.EPI_RESID_F32)]:
             a = rnd(M, K).to(dt); w = (rnd(N, K) / math.sqrt(K)).to(dt); bias = rnd(N)
             out = torch.zeros(M, N, device="cuda") if epi == nat.EPI_RESID_F32 else None
             ntiles, nk = (M // 256) * (N // 256) // 256, K // 64
-            for dbg, what in ((0, "default"), (0x90, "no residual prefetch"), (0xff, "v1 reference")):
+            for dbg, what in ((0, "default"), (0x90, "no residual prefetch")):
                 if dbg == 0x90 and epi != nat.EPI_RESID_F32:
                     continue
                 fn = lambda: ops.linear(a, w, bias, epi, out=out, dbg=dbg)
                 ms = timeit(fn, args.iters)
-                extra = stamps(fn, ntiles, nk) if dbg != 0xff else ""
+                extra = stamps(fn, ntiles, nk)
                 print(f"gemm8 {name} {what:16s}: {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TFLOP/s  {extra}", flush=True)
             del a, w, out
     if not args.only or "qkv" in args.only:
