@@ -21,6 +21,8 @@ sharding / gather logic can be exercised by the world_size-2 gloo tests without 
 import argparse
 import os
 import pathlib
+import queue
+import threading
 from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
@@ -88,6 +90,68 @@ def gather_rows(local_rows: torch.Tensor, local_index: torch.Tensor, n_total: in
     return out
 
 
+class _Writer:
+    """Background result writer: the device->host copy of batch i (on its own HIP stream, into pinned
+    buffers) and the slicing / ``torch.save`` of its sequences overlap the forward pass of batch i+1
+    (SURVEY.md §8 d: 335 MB of fp32 per 64 x 1022 batch would otherwise serialise behind the compute).
+    At most ``depth`` batches are in flight, which bounds the pinned memory."""
+
+    def __init__(self, depth=3, threads=2):
+        self.q = queue.Queue()
+        self.slots = threading.Semaphore(depth)
+        self.errors: List[BaseException] = []
+        self.threads = [threading.Thread(target=self._run, daemon=True) for _ in range(threads)]
+        for t in self.threads:
+            t.start()
+
+    def _run(self):
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            try:
+                job()
+            except BaseException as e:  # surfaced by close()
+                self.errors.append(e)
+            finally:
+                self.slots.release()
+
+    def submit(self, job):
+        self.slots.acquire()
+        if self.errors:
+            self.slots.release()
+            raise self.errors[0]
+        self.q.put(job)
+
+    def close(self):
+        for _ in self.threads:
+            self.q.put(None)
+        for t in self.threads:
+            t.join()
+        if self.errors:
+            raise self.errors[0]
+
+
+class _PinnedPool:
+    """Reusable pinned host buffers keyed by (shape, dtype): hipHostMalloc per batch would cost more than the copy."""
+
+    def __init__(self):
+        self.free: Dict[tuple, List[torch.Tensor]] = {}
+        self.lock = threading.Lock()
+
+    def take(self, like: torch.Tensor) -> torch.Tensor:
+        key = (tuple(like.shape), like.dtype)
+        with self.lock:
+            lst = self.free.get(key)
+            if lst:
+                return lst.pop()
+        return torch.empty(like.shape, dtype=like.dtype, pin_memory=True)
+
+    def give(self, t: torch.Tensor):
+        with self.lock:
+            self.free.setdefault((tuple(t.shape), t.dtype), []).append(t)
+
+
 def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool], Dict], num_layers: int,
             embed_dim: int, repr_layers: Sequence[int], include: Sequence[str],
             output_dir: Optional[pathlib.Path] = None, toks_per_batch: int = 4096,
@@ -109,6 +173,49 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
 
     my_index: List[int] = []
     my_means: Dict[int, List[torch.Tensor]] = {l: [] for l in layers}
+    lock = threading.Lock()
+
+    def batch_means(reps, strs):
+        """mean over residues 1..n of every sequence as ONE batched matmul on the tensors' device
+        (mask [B,1,T] x reps [B,T,E]); a per-sequence ``mean(0)`` on the host costs ~20 ms per 1022 x 1280 slice."""
+        any_t = next(iter(reps.values()))
+        B, T = any_t.shape[0], any_t.shape[1]
+        n = torch.tensor([min(truncation_seq_length, len(s)) for s in strs], device=any_t.device)
+        pos = torch.arange(T, device=any_t.device)[None, :]
+        mask = ((pos >= 1) & (pos <= n[:, None])).to(torch.float32)[:, None, :]  # [B,1,T]
+        return {l: (torch.bmm(mask, t.float())[:, 0, :] / n[:, None].clamp(min=1).float()) for l, t in reps.items()}
+
+    def finish(ids, labels, strs, reps, contacts, means_b):
+        """Per-sequence results of one batch from HOST tensors (reference scripts/extract.py:104-131)."""
+        rows_idx, rows_mean = [], {l: [] for l in layers}
+        for row, (seq_id, label) in enumerate(zip(ids, labels)):
+            n = min(truncation_seq_length, len(strs[row]))
+            result = {"label": label}
+            if "per_tok" in include:
+                result["representations"] = {l: t[row, 1:n + 1].clone() for l, t in reps.items()}
+            means = {l: means_b[l][row] for l in reps}
+            if "mean" in include:
+                result["mean_representations"] = {l: m.clone() for l, m in means.items()}
+            if "bos" in include:
+                result["bos_representations"] = {l: t[row, 0].clone() for l, t in reps.items()}
+            if contacts is not None:
+                result["contacts"] = contacts[row, :n, :n].clone()
+            if output_dir is not None:
+                path = output_dir / f"{label}.pt"
+                path.parent.mkdir(parents=True, exist_ok=True)
+                torch.save(result, path)
+            rows_idx.append(seq_id)
+            for l in layers:
+                rows_mean[l].append(means[l])
+        with lock:
+            my_index.extend(rows_idx)
+            for l in layers:
+                my_means[l].extend(rows_mean[l])
+
+    on_gpu = device is not None and device.type == "cuda"
+    writer = _Writer() if on_gpu else None
+    pool = _PinnedPool() if on_gpu else None
+    copy_stream = torch.cuda.Stream(device) if on_gpu else None
     with torch.no_grad():
         for n_done, bid in enumerate(plan[rank]):
             ids = batches[bid]
@@ -118,25 +225,44 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
                 toks = toks.to(device=device, non_blocking=True)
             out = embed_fn(toks, layers, return_contacts)
             reps = {l: t for l, t in out["representations"].items()}
-            for row, (seq_id, label) in enumerate(zip(ids, labels)):
-                n = min(truncation_seq_length, len(strs[row]))
-                result = {"label": label}
-                if "per_tok" in include:
-                    result["representations"] = {l: t[row, 1:n + 1].to("cpu").clone() for l, t in reps.items()}
-                means = {l: t[row, 1:n + 1].float().mean(0) for l, t in reps.items()}
-                if "mean" in include:
-                    result["mean_representations"] = {l: m.to("cpu").clone() for l, m in means.items()}
-                if "bos" in include:
-                    result["bos_representations"] = {l: t[row, 0].to("cpu").clone() for l, t in reps.items()}
-                if return_contacts:
-                    result["contacts"] = out["contacts"][row, :n, :n].to("cpu").clone()
-                if output_dir is not None:
-                    path = output_dir / f"{label}.pt"
-                    path.parent.mkdir(parents=True, exist_ok=True)
-                    torch.save(result, path)
-                my_index.append(seq_id)
-                for l in layers:
-                    my_means[l].append(means[l])
+            contacts = out["contacts"] if return_contacts else None
+            means_dev = batch_means(reps, strs)
+            if not on_gpu:
+                finish(ids, labels, strs, {l: t.to("cpu") for l, t in reps.items()},
+                       contacts.to("cpu") if contacts is not None else None, {l: m.to("cpu") for l, m in means_dev.items()})
+                continue
+            need_full = ("per_tok" in include) or ("bos" in include)
+            # device -> pinned host on the copy stream, results handled by the writer threads
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(device))
+            host_reps, host_contacts, host_means = {}, None, {}
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ready)
+                for l, t in reps.items():
+                    if not need_full:  # only the [B,E] means leave the device
+                        t = t[:, :1, :]
+                    host_reps[l] = pool.take(t)
+                    host_reps[l].copy_(t, non_blocking=True)
+                    host_means[l] = pool.take(means_dev[l])
+                    host_means[l].copy_(means_dev[l], non_blocking=True)
+                if contacts is not None:
+                    host_contacts = pool.take(contacts)
+                    host_contacts.copy_(contacts, non_blocking=True)
+                copied = torch.cuda.Event()
+                copied.record(copy_stream)
+
+            def job(ids=ids, labels=labels, strs=strs, host_reps=host_reps, host_contacts=host_contacts, copied=copied,
+                    host_means=host_means, keep_alive=(reps, contacts, means_dev)):
+                copied.synchronize()
+                finish(ids, labels, strs, host_reps, host_contacts, {l: m.clone() for l, m in host_means.items()})
+                for t in list(host_reps.values()) + list(host_means.values()):
+                    pool.give(t)
+                if host_contacts is not None:
+                    pool.give(host_contacts)
+
+            writer.submit(job)
+    if writer is not None:
+        writer.close()
     gathered: Dict[int, torch.Tensor] = {}
     if gather_mean:
         dev = device if device is not None else torch.device("cpu")
