@@ -700,7 +700,8 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.K = Kp;
         if (gemm(PC_LM_LOGITS, g, EPI_STORE_F32, 4)) return 1;
     }
-    if (want_contacts) {  // esm2.py:140-142 -> modules.py:338-357
+    if (want_contacts && T - (m->cfg.prepend_bos ? 1 : 0) - (m->cfg.append_eos ? 1 : 0) > 0) {  // esm2.py:140-142
+        // (an empty sequence has an empty [B,0,0] contact map: nothing to compute)
         ProfScope ps(m, st, PC_CONTACTS, 0, 2.0 * 4 * B * (double)L * H * T * T);
         ESMK_TRY(launch_contacts((const float*)attn_out_dev, tokens_dev, (const float*)(pk + m->ct_w),
                                  (const float*)(pk + m->ct_b), (float*)(ws + w.ct_scratch),

@@ -250,9 +250,10 @@ class ESM2(nn.Module):
                 flags |= N.OUT_ATTN
                 attn = torch.empty((B, L, H, T, T), **f32)
             if return_contacts:
-                flags |= N.OUT_CONTACTS
-                S = T - int(self.prepend_bos) - int(self.append_eos)
+                S = max(T - int(self.prepend_bos) - int(self.append_eos), 0)
                 contacts = torch.empty((B, S, S), **f32)
+                if S > 0:  # empty sequences: the reference returns an empty [B,0,0] map
+                    flags |= N.OUT_CONTACTS
             ws = eng.workspace_for(B, T, flags)
             layers_arr = (ctypes.c_int32 * max(1, len(repr_set)))(*repr_set)
             outs_arr = (ctypes.c_void_p * max(1, len(repr_set)))(*[r.data_ptr() for r in reps])

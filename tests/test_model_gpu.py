@@ -189,6 +189,51 @@ def test_head_dim_128_against_oracle():
     assert (out["contacts"].cpu() - ref["contacts"]).abs().max().item() < 8e-3
 
 
+def test_esmfold_frontend_contract():
+    """The call ESMFold makes into its language model (reference esm/esmfold/v1/esmfold.py:59-67,118-145):
+    ``esm.requires_grad_(False); esm.half()``, every layer's representation, head weights, eos placed at the
+    first padding index, then ``stack(dim=2)[:, 1:-1]`` and ``attentions.permute(0,4,3,1,2).flatten(3,4)``."""
+    L, E, H = 4, 1280, 20
+    model, sd = build(L, E, H, seed=23)
+    model.requires_grad_(False)
+    model.half()
+    B, Lmax = 2, 96
+    g = torch.Generator().manual_seed(2)
+    esmaa = torch.randint(4, 24, (B, Lmax), generator=g)
+    esmaa[1, 70:] = 1  # second protein is shorter (padding)
+    bos = esmaa.new_full((B, 1), 0)
+    eos = esmaa.new_full((B, 1), 1)
+    toks = torch.cat([bos, esmaa, eos], dim=1)
+    toks[range(B), (toks != 1).sum(1)] = 2
+    res = model(toks.cuda(), repr_layers=range(model.num_layers + 1), need_head_weights=True)
+    assert all(v.dtype == torch.float16 for v in res["representations"].values())
+    esm_s = torch.stack([v for _, v in sorted(res["representations"].items())], dim=2)[:, 1:-1]
+    esm_z = res["attentions"].permute(0, 4, 3, 1, 2).flatten(3, 4)[:, 1:-1, 1:-1, :]
+    assert esm_s.shape == (B, Lmax, L + 1, E) and esm_z.shape == (B, Lmax, Lmax, L * H)
+    ref = esm2_forward(sd, toks, L, H, repr_layers=range(L + 1), need_head_weights=True)
+    ref_s = torch.stack([v for _, v in sorted(ref["representations"].items())], dim=2)[:, 1:-1]
+    ref_z = ref["attentions"].permute(0, 4, 3, 1, 2).flatten(3, 4)[:, 1:-1, 1:-1, :]
+    valid = toks[:, 1:-1].ne(1)
+    assert rel_err(esm_s.float().cpu(), ref_s, valid) < 3e-3  # fp16 outputs on top of fp16 operands
+    assert (esm_z.float().cpu() - ref_z).abs().max().item() < 4e-3
+
+
+def test_degenerate_lengths():
+    """Empty and one-residue sequences (BatchConverter yields [cls, eos] / [cls, x, eos]): the reference returns
+    contacts of shape [B, T-2, T-2], empty for T = 2."""
+    L, E, H = 2, 128, 2
+    model, sd = build(L, E, H, seed=29)
+    for toks in (torch.tensor([[0, 2], [0, 2]]), torch.tensor([[0, 5, 2], [0, 2, 1]])):
+        with torch.no_grad():
+            out = model(toks.cuda(), repr_layers=[L], return_contacts=True)
+        ref = esm2_forward(sd, toks, L, H, repr_layers=[L], return_contacts=True)
+        T = toks.shape[1]
+        assert out["contacts"].shape == (toks.shape[0], T - 2, T - 2) == ref["contacts"].shape
+        nonpad = toks.ne(1)
+        assert rel_err(out["representations"][L].cpu(), ref["representations"][L], nonpad) < REL_SMALL
+        assert rel_err(out["logits"].cpu(), ref["logits"], nonpad) < REL_SMALL
+
+
 def test_properties_full_length():
     """Size-independent properties at L=1022 with the 650M dimensions (no oracle needed):
     run-to-run determinism, batch-composition invariance (bit exact) and padding invariance."""
