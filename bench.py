@@ -141,7 +141,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16",
+            "dtype": "bf16" if os.environ.get("ESM_AMD_OPERAND", "").lower() in ("bf16", "bfloat16") else "f16",
             "data": "synthetic",
             "config": {
                 "workload": f"{MODEL} forward (repr_layers=[33] + logits), synthetic tokens [B,{args.seq_len + 2}], "

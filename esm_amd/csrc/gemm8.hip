@@ -774,6 +774,11 @@ static hipError_t launch8(GemmArgs p, hipStream_t st) {
         attr_set = true;
     }
     const int tiles_n = (p.N + 255) / 256;
+    static const int env_panel = [] {
+        const char* e = getenv("ESMK_PANEL_C");
+        return e ? atoi(e) : 0;
+    }();
+    if (p.panel_c <= 0 && env_panel > 0) p.panel_c = env_panel < tiles_n ? env_panel : tiles_n;
     if (p.panel_c <= 0) {
         // 32 concurrent tiles per XCD should form a block as square as possible: ~6 x 5 or 8 x 4
         if (tiles_n <= 6) p.panel_c = tiles_n;
