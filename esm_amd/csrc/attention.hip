@@ -51,8 +51,8 @@ ESMK_DEV void attn_barrier() {
 
 // STAGES: LDS buffers of the K / V^T stream (2: one tile in flight, drained every tile; 3: two tiles in
 // flight behind a counted vmcnt).  TREE: 4-way split max / sum reductions.  xcdmap: see the file header.
-template <typename T, int STAGES, int TREE>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
+template <typename T, int STAGES, int TREE, int MINW = 2>
+__global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
     const float* __restrict__ key_bias, const int* __restrict__ seq_info, T* __restrict__ ctx,
     float* __restrict__ lse, int H, int BH, int nq, int Tlen, int Tp, int xcdmap, int fill_mode,
@@ -552,6 +552,10 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
     hipLaunchKernelGGL((attn_fwd_kernel<TT, ST, TR>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k, \
                        (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad)
 #define ESMK_ATTN_VARIANTS(TT)                                   \
+    if (var & 16) {  /* <= 128 VGPRs: four waves per SIMD */     \
+        hipLaunchKernelGGL((attn_fwd_kernel<TT, 2, 0, 4>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k, \
+                           (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad); \
+    } else                                                       \
     switch ((var >> 1) & 3) {                                    \
         case 0: ESMK_ATTN_LAUNCH(TT, 2, 0); break;               \
         case 1: ESMK_ATTN_LAUNCH(TT, 3, 0); break;               \

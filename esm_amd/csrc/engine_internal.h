@@ -1,0 +1,89 @@
+// engine_internal.h — state shared by the host-side translation units of libesmk.so (engine.hip: ESM-2 /
+// ESM-1b path and the generic C ABI; engine_msa.hip: MSA Transformer path).  Not part of the public ABI.
+#pragma once
+#include "../../include/esmk.h"
+#include "kernels.h"
+
+#include <string>
+#include <vector>
+
+namespace esmk_host {
+
+// error reporting: message kept per thread for esmk_last_error()
+int fail(const char* what, hipError_t e);
+int fail(const std::string& msg);
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+inline size_t op_size(int dt) { return dt == esmk::ESMK_DT_F32 ? 4 : 2; }
+
+// sequential carving of byte offsets (256-byte aligned) out of one buffer
+struct Carve {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        size_t o = off;
+        off = align_up(off + bytes);
+        return o;
+    }
+};
+
+// packed-parameter offsets of one TransformerLayer (reference esm/modules.py:84-142)
+struct LayerOff {
+    size_t wqkv, bqkv, wo, bo, w1, b1, w2, b2, ln1g, ln1b, ln2g, ln2b;
+};
+// one AxialTransformerLayer (reference esm/modules.py:145-221)
+struct AttnOff {
+    size_t wqkv, bqkv, wo, bo, lng, lnb;
+};
+struct MsaLayerOff {
+    AttnOff row, col;
+    size_t w1, b1, w2, b2, flng, flnb;
+};
+
+}  // namespace esmk_host
+
+#define ESMK_TRY(expr)                                             \
+    do {                                                           \
+        hipError_t _e = (expr);                                    \
+        if (_e != hipSuccess) return esmk_host::fail(#expr, _e);   \
+    } while (0)
+
+struct esmk_model {
+    esmk_config cfg;
+    int L, E, H, F, V, D;
+    int EA = 0;  // attention width inside the engine: H * 64 (heads with head_dim < 64 are spread over 64 slots)
+    int Kp = 0;  // E rounded up to the 64-wide K tile: row stride of the normalised activations
+    // packed parameter image layout (byte offsets)
+    size_t embed_f32, embed_op, fin_g, fin_b, lm_w, lm_b, lm_lng, lm_lnb, lm_bias, ct_w, ct_b;
+    std::vector<esmk_host::LayerOff> layer;
+    size_t packed_bytes;
+    // RoPE
+    std::vector<float> inv_freq;
+    float* d_inv_freq = nullptr;
+    float* d_cos = nullptr;
+    float* d_sin = nullptr;
+    int rope_cap = 0;
+    // optional per-kernel-class timing with HIP events (esmk_profile_begin / _end)
+    struct ProfRec {
+        int cls;
+        hipEvent_t a, b;
+        double flops, bytes;
+    };
+    bool prof_on = false;
+    std::vector<ProfRec> prof;
+    // MSA Transformer (esmk_msa_create)
+    bool is_msa = false;
+    int npos = 0, has_msa_pos = 0;
+    size_t pos_emb = 0, msa_pos = 0, lnb_g = 0, lnb_b = 0;
+    std::vector<esmk_host::MsaLayerOff> mlayer;
+    float* d_ucos = nullptr;  // "unit" rotary tables (cos = 1, sin = 0): the MSA model has no RoPE
+    float* d_usin = nullptr;
+    int unit_cap = 0;
+};
+
+
+namespace esmk_host {
+// "unit" rotary tables (cos = 1, sin = 0) for models without RoPE (MSA Transformer, ESM-1b)
+int ensure_unit_rope(esmk_model* m, int T, hipStream_t st);
+// packed image layout of the MSA Transformer (engine_msa.hip)
+void plan_packed_msa(esmk_model* m);
+}  // namespace esmk_host

@@ -1,0 +1,408 @@
+// engine_msa.hip — host side of the MSA Transformer path of libesmk.so (declared in include/esmk.h):
+// packed parameter layout, workspace planning and the launch sequence that replaces MSATransformer.forward
+// (reference esm/model/msa_transformer.py:146-220).  Kernels live in gemm8.hip, attention.hip, elementwise.hip.
+#include "engine_internal.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+
+using namespace esmk;
+using namespace esmk_host;
+
+namespace esmk_host {
+void plan_packed_msa(esmk_model* m) {
+    const size_t os = op_size(m->cfg.operand_dtype);
+    const size_t E = m->E, F = m->F, V = m->V;
+    Carve c;
+    m->embed_f32 = c.take(V * E * 4);
+    m->embed_op = c.take(V * E * os);
+    m->pos_emb = c.take((size_t)m->npos * E * 4);
+    m->msa_pos = c.take((size_t)1024 * E * 4);
+    m->lnb_g = c.take(E * 4);
+    m->lnb_b = c.take(E * 4);
+    m->fin_g = c.take(E * 4);
+    m->fin_b = c.take(E * 4);
+    m->lm_w = c.take(E * E * os);
+    m->lm_b = c.take(E * 4);
+    m->lm_lng = c.take(E * 4);
+    m->lm_lnb = c.take(E * 4);
+    m->lm_bias = c.take(V * 4);
+    m->ct_w = c.take((size_t)m->L * m->H * 4);
+    m->ct_b = c.take(4);
+    m->mlayer.resize(m->L);
+    auto attn = [&](AttnOff& a) {
+        a.wqkv = c.take(3 * E * E * os);
+        a.bqkv = c.take(3 * E * 4);
+        a.wo = c.take(E * E * os);
+        a.bo = c.take(E * 4);
+        a.lng = c.take(E * 4);
+        a.lnb = c.take(E * 4);
+    };
+    for (int l = 0; l < m->L; ++l) {
+        MsaLayerOff& o = m->mlayer[l];
+        attn(o.row);
+        attn(o.col);
+        o.w1 = c.take(F * E * os);
+        o.b1 = c.take(F * 4);
+        o.w2 = c.take(E * F * os);
+        o.b2 = c.take(E * 4);
+        o.flng = c.take(E * 4);
+        o.flnb = c.take(E * 4);
+    }
+    m->packed_bytes = c.off;
+}
+}  // namespace esmk_host
+
+// =============================================================================================
+// MSA Transformer (reference esm/model/msa_transformer.py, esm/axial_attention.py)
+// =============================================================================================
+namespace {
+
+struct MsaWorkspace {
+    size_t keep, col_fill, any_pad, x, h, big, scores, probs, lse, ct_scratch, total;
+    size_t q, k, vt;  // inside big
+    int Cp, Rp;
+};
+
+MsaWorkspace plan_msa_workspace(const esmk_model* m, int B, int R, int C, uint32_t flags) {
+    MsaWorkspace w{};
+    const size_t os = op_size(m->cfg.operand_dtype);
+    const size_t N = (size_t)B * R * C, E = m->E, F = m->F, H = m->H;
+    w.Cp = (C + 63) / 64 * 64;
+    w.Rp = (R + 63) / 64 * 64;
+    Carve c;
+    w.keep = c.take(N * 4);
+    w.col_fill = c.take(N * 4);
+    w.any_pad = c.take(256);
+    w.x = c.take(N * E * 4);
+    w.h = c.take(N * E * os + 4096);
+    const size_t qb = align_up(N * E * os + 4096);
+    const size_t vt_row = (size_t)B * H * R * 64 * w.Cp * os;         // [B,H,R,64,Cp]
+    const size_t vt_col = (size_t)B * C * H * 64 * w.Rp * os;         // [B*C,H,64,Rp]
+    size_t big = 2 * qb + align_up(std::max(vt_row, vt_col));
+    big = std::max(big, N * F * os);
+    big = std::max(big, N * E * 4);
+    w.big = c.take(big);
+    w.q = w.big;
+    w.k = w.big + qb;
+    w.vt = w.big + 2 * qb;
+    w.scores = c.take((size_t)B * H * C * w.Cp * 4);
+    w.probs = c.take((size_t)B * H * C * w.Cp * os);
+    w.lse = c.take((flags & ESMK_OUT_COL_ATTN) ? (size_t)B * C * H * R * 4 : 0);
+    const int S = C - (m->cfg.prepend_bos ? 1 : 0) - (m->cfg.append_eos ? 1 : 0);
+    w.ct_scratch =
+        c.take((flags & ESMK_OUT_CONTACTS) ? (size_t)B * m->L * m->H * (size_t)(S > 0 ? S + 1 : 1) * 4 : 0);
+    w.total = c.off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int esmk_msa_create(const esmk_msa_config* cfg, esmk_model** out) {
+    if (!cfg || !out) return fail("esmk_msa_create: null argument");
+    if (cfg->num_layers <= 0 || cfg->embed_dim <= 0 || cfg->num_heads <= 0 || cfg->ffn_dim <= 0 ||
+        cfg->vocab <= 0 || cfg->num_positions <= 0)
+        return fail("esmk_msa_create: non-positive dimension");
+    if (cfg->embed_dim % cfg->num_heads != 0 || cfg->embed_dim / cfg->num_heads != 64)
+        return fail("esmk_msa_create: head_dim must be 64 for the gfx950 attention kernels");
+    if (cfg->embed_dim % 64 != 0 || cfg->ffn_dim % 64 != 0)
+        return fail("esmk_msa_create: embed_dim and ffn_dim must be multiples of 64");
+    if (cfg->operand_dtype != ESMK_F16 && cfg->operand_dtype != ESMK_BF16)
+        return fail("esmk_msa_create: operand_dtype must be ESMK_F16 or ESMK_BF16");
+    esmk_model* m = new esmk_model();
+    memset(&m->cfg, 0, sizeof(m->cfg));
+    m->cfg.num_layers = cfg->num_layers;
+    m->cfg.embed_dim = cfg->embed_dim;
+    m->cfg.num_heads = cfg->num_heads;
+    m->cfg.ffn_dim = cfg->ffn_dim;
+    m->cfg.vocab = cfg->vocab;
+    m->cfg.pad_idx = cfg->pad_idx;
+    m->cfg.mask_idx = cfg->mask_idx;
+    m->cfg.cls_idx = cfg->cls_idx;
+    m->cfg.eos_idx = cfg->eos_idx;
+    m->cfg.prepend_bos = cfg->prepend_bos;
+    m->cfg.append_eos = cfg->append_eos;
+    m->cfg.operand_dtype = cfg->operand_dtype;
+    m->L = cfg->num_layers;
+    m->E = cfg->embed_dim;
+    m->H = cfg->num_heads;
+    m->F = cfg->ffn_dim;
+    m->V = cfg->vocab;
+    m->D = 64;
+    m->EA = m->E;
+    m->Kp = m->E;
+    m->is_msa = true;
+    m->npos = cfg->num_positions;
+    m->has_msa_pos = cfg->has_msa_position_embedding;
+    plan_packed_msa(m);
+    *out = m;
+    return 0;
+}
+
+int esmk_msa_workspace_bytes(const esmk_model* m, int B, int R, int C, uint32_t out_flags, size_t* bytes) {
+    if (!m || !bytes || !m->is_msa) return fail("esmk_msa_workspace_bytes: not an MSA model handle");
+    if (B <= 0 || R <= 0 || C <= 0) return fail("esmk_msa_workspace_bytes: B, R, C must be positive");
+    *bytes = plan_msa_workspace(m, B, R, C, out_flags).total;
+    return 0;
+}
+
+int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_dev, int B, int R, int C,
+                     const int32_t* repr_layers, int n_repr, void* const* repr_out_dev, uint32_t out_flags,
+                     void* logits_out_dev, void* row_attn_out_dev, void* col_attn_out_dev,
+                     void* contacts_out_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+    if (!m || !m->is_msa) return fail("esmk_msa_forward: not an MSA model handle");
+    if (!packed_dev || !tokens_dev || !workspace_dev) return fail("esmk_msa_forward: null argument");
+    if (B <= 0 || R <= 0 || C <= 0) return fail("esmk_msa_forward: B, R, C must be positive");
+    if (R > 1024 && m->has_msa_pos)
+        return fail("esmk_msa_forward: MSA position embedding covers a depth of 1024 alignments");  // msa_transformer.py:160-164
+    if (C > 1024) return fail("esmk_msa_forward: more than 1024 columns are not supported");
+    if (C > m->npos - m->cfg.pad_idx - 1)
+        return fail("esmk_msa_forward: sequence length above the maximum of the positional embedding");  // modules.py:243-247
+    const bool want_logits = out_flags & ESMK_OUT_LOGITS;
+    const bool want_contacts = out_flags & ESMK_OUT_CONTACTS;
+    const bool want_attn = (out_flags & ESMK_OUT_ATTN) || want_contacts;
+    if (want_logits && !logits_out_dev) return fail("esmk_msa_forward: logits buffer missing");
+    if (want_attn && !row_attn_out_dev) return fail("esmk_msa_forward: row attention buffer missing");
+    if (want_contacts && !contacts_out_dev) return fail("esmk_msa_forward: contacts buffer missing");
+    const bool want_col = out_flags & ESMK_OUT_COL_ATTN;
+    if (want_col && !col_attn_out_dev) return fail("esmk_msa_forward: column attention buffer missing");
+    for (int i = 0; i < n_repr; ++i)
+        if (repr_layers[i] < 0 || repr_layers[i] > m->L || !repr_out_dev[i])
+            return fail("esmk_msa_forward: bad repr layer request");
+    const MsaWorkspace w = plan_msa_workspace(m, B, R, C, out_flags);
+    if (workspace_bytes < w.total) return fail("esmk_msa_forward: workspace too small");
+
+    hipStream_t st = (hipStream_t)stream;
+    const int op = m->cfg.operand_dtype;
+    const size_t os = op_size(op);
+    const int N = B * R * C, E = m->E, F = m->F, H = m->H, L = m->L, Cp = w.Cp, Rp = w.Rp;
+    char* ws = (char*)workspace_dev;
+    const char* pk = (const char*)packed_dev;
+    float* keep = (float*)(ws + w.keep);
+    float* col_fill = (float*)(ws + w.col_fill);
+    int* any_pad = (int*)(ws + w.any_pad);
+    float* x = (float*)(ws + w.x);
+    void* h = ws + w.h;
+    void* q = ws + w.q;
+    void* k = ws + w.k;
+    void* vt = ws + w.vt;
+    void* ffn = ws + w.big;
+    float* g32 = (float*)(ws + w.big);
+    float* scores = (float*)(ws + w.scores);
+    void* probs = ws + w.probs;
+    if (ensure_unit_rope(m, std::max(R, C), st)) return 1;
+
+    auto repr_copy = [&](int layer, const float* src) -> int {
+        for (int i = 0; i < n_repr; ++i)
+            if (repr_layers[i] == layer)
+                ESMK_TRY(launch_copy_f32(src, (float*)repr_out_dev[i], (size_t)N * E, st));
+        return 0;
+    };
+    auto gemm = [&](const GemmArgs& a, int epi) -> int {
+        ESMK_TRY(launch_gemm(a, epi, op, st));
+        return 0;
+    };
+
+    // msa_transformer.py:152-172: token + position + MSA-row embeddings, LayerNorm, pads zeroed
+    ESMK_TRY(launch_msa_embed(tokens_dev, (const float*)(pk + m->embed_f32), (const float*)(pk + m->pos_emb),
+                              m->has_msa_pos ? (const float*)(pk + m->msa_pos) : nullptr, x, keep, col_fill,
+                              any_pad, B, R, C, E, m->V, m->cfg.pad_idx, m->npos, st));
+    {
+        LnExtra ex;
+        ex.row_keep = keep;
+        ESMK_TRY(launch_layernorm_ex(x, (const float*)(pk + m->lnb_g), (const float*)(pk + m->lnb_b), nullptr, x,
+                                     N, E, op, ex, st));
+    }
+    if (repr_copy(0, x)) return 1;
+
+    // q/k/v projections of one axial attention block on `rows` = N rows grouped in sequences of T tokens
+    auto qkv = [&](const AttnOff& a, int T, int Tp, float scaling, const float* row_keep, int vt_rows) -> int {
+        GemmArgs g;
+        g.A = h;
+        g.W = pk + a.wqkv;
+        g.bias = (const float*)(pk + a.bqkv);
+        g.M = N;
+        g.N = 2 * E;
+        g.K = E;
+        g.q = q;
+        g.k = k;
+        g.vt = vt;
+        g.cos = m->d_ucos;
+        g.sin = m->d_usin;
+        g.T = T;
+        g.H = H;
+        g.E = E;
+        g.Tp = Tp;
+        g.scaling = scaling;
+        g.row_keep = row_keep;
+        if (gemm(g, EPI_QKV_ROPE)) return 1;
+        g.row_keep = nullptr;
+        g.W = pk + a.wqkv + (size_t)2 * E * E * os;
+        g.bias = (const float*)(pk + a.bqkv) + 2 * E;
+        g.N = E;
+        g.vt_rows = vt_rows;
+        return gemm(g, EPI_V_T);
+    };
+    auto out_proj = [&](const AttnOff& a, int map_R, int map_C) -> int {
+        GemmArgs g;
+        g.A = h;
+        g.W = pk + a.wo;
+        g.bias = (const float*)(pk + a.bo);
+        g.out = x;
+        g.M = N;
+        g.N = E;
+        g.K = E;
+        g.rowmap_R = map_R;
+        g.rowmap_C = map_C;
+        return gemm(g, EPI_RESID_F32);
+    };
+
+    for (int l = 0; l < L; ++l) {
+        const MsaLayerOff& o = m->mlayer[l];
+        // ---- tied row attention (axial_attention.py:75-130; NormalizedResidualBlock modules.py:376-392) ----
+        ESMK_TRY(launch_layernorm(x, (const float*)(pk + o.row.lng), (const float*)(pk + o.row.lnb), h, nullptr, N,
+                                  E, op, st));
+        if (Cp != C) ESMK_TRY(hipMemsetAsync(vt, 0, (size_t)B * H * R * 64 * Cp * os, st));
+        // sequences = MSA rows (b,r) of C tokens; q scaled by d^-1/2 / sqrt(R) (axial_attention.py:36-38)
+        if (qkv(o.row, C, Cp, (1.0f / sqrtf(64.0f)) / sqrtf((float)R), keep, R)) return 1;
+        {   // scores[b,h,i,j] = sum_{r,d} q[r,i,b,h,d] k[r,j,b,h,d]   (axial_attention.py:90): K tile r of
+            // the batched GEMM is the [C,64] matrix q[(b,r),h] (row stride 128 B)
+            GemmArgs g;
+            g.A = q;
+            g.W = k;
+            g.out = scores;
+            g.M = C;
+            g.N = Cp;
+            g.n_valid = C;
+            g.K = R * 64;
+            g.ldc = Cp;
+            g.a_row_bytes = g.w_row_bytes = 128;
+            g.a_kt_bytes = g.w_kt_bytes = (long long)H * C * 64 * os;
+            g.batch = B * H;
+            g.batch_inner = H;
+            g.a_bo = g.w_bo = (long long)R * H * C * 64 * os;
+            g.a_bi = g.w_bi = (long long)C * 64 * os;
+            g.o_bo = (long long)H * C * Cp * 4;
+            g.o_bi = (long long)C * Cp * 4;
+            if (gemm(g, EPI_STORE_F32)) return 1;
+        }
+        ESMK_TRY(launch_msa_row_softmax(scores, keep, any_pad, probs, want_attn ? (float*)row_attn_out_dev : nullptr,
+                                        B, H, R, C, Cp, l, L, op, st));
+        {   // context[r,i,b,h,:] = sum_j probs[h,b,i,j] v[r,j,b,h,:]   (axial_attention.py:111)
+            GemmArgs g;
+            g.A = probs;
+            g.W = vt;
+            g.out = h;
+            g.M = C;
+            g.N = R * 64;
+            g.K = Cp;
+            g.ldc = E;
+            g.a_row_bytes = g.w_row_bytes = (long long)Cp * os;
+            g.batch = B * H;
+            g.batch_inner = H;
+            g.a_bo = (long long)H * C * Cp * os;
+            g.a_bi = (long long)C * Cp * os;
+            g.w_bo = (long long)H * R * 64 * Cp * os;
+            g.w_bi = (long long)R * 64 * Cp * os;
+            g.ctx_R = R;
+            g.ctx_C = C;
+            if (gemm(g, EPI_MSA_CTX)) return 1;
+        }
+        if (out_proj(o.row, 0, 0)) return 1;
+
+        // ---- column attention (axial_attention.py:185-239): every MSA column (b,c) is a sequence of R rows;
+        // the normalised rows are written in (b,c,r) order so the ESM-2 attention path applies unchanged ----
+        {
+            LnExtra ex;
+            ex.map_R = R;
+            ex.map_C = C;
+            ESMK_TRY(launch_layernorm_ex(x, (const float*)(pk + o.col.lng), (const float*)(pk + o.col.lnb), h, nullptr,
+                                         N, E, op, ex, st));
+        }
+        if (Rp != R) ESMK_TRY(hipMemsetAsync(vt, 0, (size_t)B * C * H * 64 * Rp * os, st));
+        if (qkv(o.col, R, Rp, 1.0f / sqrtf(64.0f), nullptr, 0)) return 1;
+        float* lse = want_col ? (float*)(ws + w.lse) : nullptr;
+        ESMK_TRY(launch_attention_fill(q, k, vt, col_fill, any_pad, h, lse, B * C, H, R, Rp, op, st));
+        if (want_col)
+            ESMK_TRY(launch_attention_probs_msa(q, k, lse, col_fill, any_pad, (float*)col_attn_out_dev, B, C, H, R, l,
+                                                L, op, st));
+        if (out_proj(o.col, R, C)) return 1;
+
+        // ---- feed forward (modules.py:395-418) ----
+        ESMK_TRY(launch_layernorm(x, (const float*)(pk + o.flng), (const float*)(pk + o.flnb), h, nullptr, N, E, op, st));
+        {
+            GemmArgs g;
+            g.A = h;
+            g.W = pk + o.w1;
+            g.bias = (const float*)(pk + o.b1);
+            g.out = ffn;
+            g.M = N;
+            g.N = F;
+            g.K = E;
+            if (gemm(g, EPI_GELU_T)) return 1;
+            g = GemmArgs();
+            g.A = ffn;
+            g.W = pk + o.w2;
+            g.bias = (const float*)(pk + o.b2);
+            g.out = x;
+            g.M = N;
+            g.N = E;
+            g.K = F;
+            if (gemm(g, EPI_RESID_F32)) return 1;
+        }
+        if (l + 1 < L && repr_copy(l + 1, x)) return 1;  // msa_transformer.py:197-198
+    }
+
+    // msa_transformer.py:200-206: final LayerNorm (representation L is the normalised stream), LM head
+    float* rep_last = nullptr;
+    bool wants_last = false;
+    for (int i = 0; i < n_repr; ++i)
+        if (repr_layers[i] == L) {
+            wants_last = true;
+            if (!rep_last) rep_last = (float*)repr_out_dev[i];
+        }
+    if (want_logits || wants_last) {
+        ESMK_TRY(launch_layernorm(x, (const float*)(pk + m->fin_g), (const float*)(pk + m->fin_b),
+                                  want_logits ? h : nullptr, rep_last, N, E, op, st));
+        for (int i = 0; i < n_repr; ++i)
+            if (repr_layers[i] == L && repr_out_dev[i] != rep_last)
+                ESMK_TRY(launch_copy_f32(rep_last, (float*)repr_out_dev[i], (size_t)N * E, st));
+    }
+    if (want_logits) {  // modules.py:308-314
+        GemmArgs g;
+        g.A = h;
+        g.W = pk + m->lm_w;
+        g.bias = (const float*)(pk + m->lm_b);
+        g.out = g32;
+        g.M = N;
+        g.N = E;
+        g.K = E;
+        if (gemm(g, EPI_GELU_F32)) return 1;
+        ESMK_TRY(launch_layernorm(g32, (const float*)(pk + m->lm_lng), (const float*)(pk + m->lm_lnb), h, nullptr, N, E,
+                                  op, st));
+        g = GemmArgs();
+        g.A = h;
+        g.W = pk + m->embed_op;
+        g.bias = (const float*)(pk + m->lm_bias);
+        g.out = logits_out_dev;
+        g.M = N;
+        g.N = m->V;
+        g.K = E;
+        if (gemm(g, EPI_STORE_F32)) return 1;
+    }
+    if (want_contacts) {  // msa_transformer.py:215-217 -> modules.py:338-357 on the row attentions
+        // the contact head reads tokens only for the <eos> mask, which the MSA alphabet does not append
+        ESMK_TRY(launch_contacts((const float*)row_attn_out_dev, tokens_dev, (const float*)(pk + m->ct_w),
+                                 (const float*)(pk + m->ct_b), (float*)(ws + w.ct_scratch),
+                                 (float*)contacts_out_dev, B, L * H, C, m->cfg.eos_idx, m->cfg.prepend_bos,
+                                 m->cfg.append_eos, st));
+    }
+    return 0;
+}
+
+}  // extern "C"
