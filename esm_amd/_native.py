@@ -70,6 +70,15 @@ SIGNATURES = {
             c_void_p, c_size_t, c_void_p,
         ],
     ),
+    "esmk_packed_workspace_bytes": (c_int, [c_void_p, c_int, c_int, c_uint32, POINTER(c_size_t)]),
+    "esmk_forward_packed": (
+        c_int,
+        [
+            c_void_p, c_void_p, c_void_p, POINTER(c_int32), c_int, c_int,
+            POINTER(c_int32), c_int, POINTER(c_void_p),
+            c_uint32, c_void_p, c_void_p, c_size_t, c_void_p,
+        ],
+    ),
     "esmk_msa_create": (c_int, [POINTER(EsmkMsaConfig), POINTER(c_void_p)]),
     "esmk_msa_workspace_bytes": (c_int, [c_void_p, c_int, c_int, c_int, c_uint32, POINTER(c_size_t)]),
     "esmk_msa_forward": (

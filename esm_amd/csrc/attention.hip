@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
     const float* __restrict__ key_bias, const int* __restrict__ seq_info, T* __restrict__ ctx,
     float* __restrict__ lse, int H, int BH, int nq, int Tlen, int Tp, int xcdmap, int fill_mode,
-    const int* __restrict__ any_pad) {
+    const int* __restrict__ any_pad, AttnSegs segs) {
     __shared__ __attribute__((aligned(16))) char smem[STAGES * A_STAGE];
     using V8 = typename Op<T>::v8;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -78,12 +78,28 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(
         }
     }
     const int b = bh / H, head = bh - b * H;
-    const int q0 = qblk * 128 + wave * 32;
+    // Token-packed batches (segs.work != null; esmk_forward_packed): the "sequence" is one row space of Tlen
+    // rows holding the segments back to back, and query block qblk is work item (first row of its segment,
+    // segment length, first query of the block relative to the segment, segment index).  Keys, values and
+    // the softmax stay inside the segment: same tiles, same order as the segment alone => same bits.
+    int row0 = 0, Tseg = Tlen, qrel = qblk * 128;
+    bool seg_pad = false;
+    if (segs.work != nullptr) {
+        row0 = __builtin_amdgcn_readfirstlane(segs.work[4 * qblk]);
+        Tseg = __builtin_amdgcn_readfirstlane(segs.work[4 * qblk + 1]);
+        qrel = __builtin_amdgcn_readfirstlane(segs.work[4 * qblk + 2]);
+        seg_pad = segs.npad[__builtin_amdgcn_readfirstlane(segs.work[4 * qblk + 3])] > 0;
+    }
+    const int q0 = qrel + wave * 32;
+    const size_t rbase = (size_t)bh * Tlen + row0;  // first row of the segment in the [BH, Tlen] row spaces
 
     // padding information of this sequence (wave uniform)
-    int kv_end = Tlen;
-    bool use_mask = (Tlen & 63) != 0;
-    if (fill_mode) {
+    int kv_end = Tseg;
+    bool use_mask = (Tseg & 63) != 0;
+    if (segs.work != nullptr) {
+        if (seg_pad) use_mask = true;  // <pad> tokens inside the segment
+        else key_bias = nullptr;
+    } else if (fill_mode) {
         // MSA column attention: key_bias holds 0/1 fill flags, used only when the batch has a pad
         if (key_bias != nullptr && any_pad != nullptr && any_pad[0] != 0) use_mask = true;
         else key_bias = nullptr;
@@ -99,14 +115,14 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(
     }
     const int ntiles = (kv_end + 63) >> 6;
 
-    const T* kb = k + (size_t)bh * Tlen * 64;
-    const T* vb = vt + (size_t)bh * 64 * Tp;
+    const T* kb = k + rbase * 64;
+    const T* vb = vt + (size_t)bh * 64 * Tp + row0;
 
     // Q fragments: Q[q0 + lm][16 ks + 8 h .. +7]
     V8 qf[4];
     {
-        const int qr = min(q0 + lm, Tlen - 1);
-        const T* qp = q + ((size_t)bh * Tlen + qr) * 64 + 8 * h;
+        const int qr = min(q0 + lm, Tseg - 1);
+        const T* qp = q + (rbase + qr) * 64 + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qp + 16 * ks);
     }
@@ -129,15 +145,15 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(
         const int k0 = kt * 64;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int kr = min(k0 + krow[j], Tlen - 1);
+            const int kr = min(k0 + krow[j], Tseg - 1);
             glds16(gk[j] + (size_t)kr * 64, base + (j * 256 + wave * 64) * 16);
             glds16(gv[j] + k0, base + A_TILE + (j * 256 + wave * 64) * 16);
         }
         if (use_mask && tid < 64) {
             const int key = k0 + tid;
             float bv = -INFINITY;  // keys past the end of the row: excluded
-            if (key < Tlen) {
-                bv = key_bias ? key_bias[(size_t)b * Tlen + key] : 0.f;
+            if (key < Tseg) {
+                bv = key_bias ? key_bias[(size_t)b * Tlen + row0 + key] : 0.f;
                 // fill flag -> +inf marker: the score is REPLACED by -10000 (masked_fill, axial_attention.py:211-215)
                 if (fill_mode) bv = (bv != 0.f) ? INFINITY : 0.f;
             }
@@ -283,17 +299,17 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(
             for (int e = 0; e < 4; ++e) pk[e] = Op<T>::from(o[d][4 * g + e] * inv);
             *reinterpret_cast<V4*>(wl + lm * 128 + (((4 * d + g) ^ (lm & 7)) << 4) + 8 * h) = pk;
         }
-    T* dst = ctx + ((size_t)b * Tlen) * ((size_t)H * 64) + head * 64;
+    T* dst = ctx + ((size_t)b * Tlen + row0) * ((size_t)H * 64) + head * 64;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int pc = it * 64 + lane;
         const int r = pc >> 3, c = pc & 7;
         const V8 v = *reinterpret_cast<const V8*>(wl + r * 128 + ((c ^ (r & 7)) << 4));
-        if (q0 + r < Tlen) *reinterpret_cast<V8*>(dst + (size_t)(q0 + r) * ((size_t)H * 64) + c * 8) = v;
+        if (q0 + r < Tseg) *reinterpret_cast<V8*>(dst + (size_t)(q0 + r) * ((size_t)H * 64) + c * 8) = v;
     }
     const int qrow = q0 + lm;
-    if (lse != nullptr && h == 0 && qrow < Tlen)
-        lse[(size_t)bh * Tlen + qrow] = m2 * (1.0f / LOG2E) + logf(ltot);
+    if (lse != nullptr && h == 0 && qrow < Tseg)
+        lse[rbase + qrow] = m2 * (1.0f / LOG2E) + logf(ltot);
 }
 
 
@@ -523,7 +539,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(
 
 static hipError_t launch_attention_impl(const void* q, const void* k, const void* vt, const float* key_bias,
                                         const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
-                                        int operand_dtype, int fill_mode, const int* any_pad, hipStream_t st);
+                                        int operand_dtype, int fill_mode, const int* any_pad, hipStream_t st,
+                                        AttnSegs segs = AttnSegs(), int n_items = 0);
 
 hipError_t launch_attention(const void* q, const void* k, const void* vt, const float* key_bias,
                             const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
@@ -537,11 +554,21 @@ hipError_t launch_attention_fill(const void* q, const void* k, const void* vt, c
     return launch_attention_impl(q, k, vt, key_fill, nullptr, ctx, lse, B, H, T, Tp, operand_dtype, 1, any_pad, st);
 }
 
+// token-packed batch: one row space of `rows` rows, `n_items` query blocks described by segs.work
+hipError_t launch_attention_packed(const void* q, const void* k, const void* vt, const float* key_bias, void* ctx,
+                                   int H, int rows, int Tp, AttnSegs segs, int n_items, int operand_dtype,
+                                   hipStream_t st) {
+    if (segs.work == nullptr || segs.npad == nullptr || n_items <= 0) return hipErrorInvalidValue;
+    return launch_attention_impl(q, k, vt, key_bias, nullptr, ctx, nullptr, 1, H, rows, Tp, operand_dtype, 0, nullptr,
+                                 st, segs, n_items);
+}
+
 static hipError_t launch_attention_impl(const void* q, const void* k, const void* vt, const float* key_bias,
                                         const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
-                                        int operand_dtype, int fill_mode, const int* any_pad, hipStream_t st) {
+                                        int operand_dtype, int fill_mode, const int* any_pad, hipStream_t st,
+                                        AttnSegs segs, int n_items) {
     if (B <= 0 || H <= 0 || T <= 0 || Tp < T || (Tp & 63)) return hipErrorInvalidValue;
-    const int nq = (T + 127) / 128;
+    const int nq = segs.work != nullptr ? n_items : (T + 127) / 128;
     dim3 grid(nq * B * H);
     // ESMK_ATTN (read once): bit 0 XCD-grouped grid, bit 1 three LDS stages, bit 2 split reductions
     static const int var = [] {
@@ -550,11 +577,11 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
     }();
 #define ESMK_ATTN_LAUNCH(TT, ST, TR)                                                                    \
     hipLaunchKernelGGL((attn_fwd_kernel<TT, ST, TR>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k, \
-                       (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad)
+                       (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad, segs)
 #define ESMK_ATTN_VARIANTS(TT)                                   \
     if (var & 16) {  /* <= 128 VGPRs: four waves per SIMD */     \
         hipLaunchKernelGGL((attn_fwd_kernel<TT, 2, 0, 4>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k, \
-                           (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad); \
+                           (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad, segs); \
     } else                                                       \
     switch ((var >> 1) & 3) {                                    \
         case 0: ESMK_ATTN_LAUNCH(TT, 2, 0); break;               \
@@ -562,6 +589,7 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
         case 2: ESMK_ATTN_LAUNCH(TT, 2, 1); break;               \
         default: ESMK_ATTN_LAUNCH(TT, 3, 1); break;              \
     }
+    if ((var & 8) && segs.work != nullptr) return hipErrorInvalidValue;  // the 64-rows-per-wave variant is dense only
     if (var & 8) {  // 64 query rows per wave
         const int nq2 = (T + 255) / 256;
         dim3 grid2(nq2 * B * H);

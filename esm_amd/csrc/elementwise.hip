@@ -68,6 +68,64 @@ hipError_t launch_seq_stats(const int64_t* tokens, int B, int T, int pad_idx, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// token-packed batches (esmk_forward_packed): the same statistics per SEGMENT of one packed row space.
+// Workgroup s < n_seg handles segment s (rows [seg[2s], seg[2s] + seg[2s+1])) and the gap behind it (up to the
+// next segment's first row, or `rows` after the last one).  The token-dropout divisor of esm2.py:91-92 is
+// written per ROW so the embedding kernel can run with "sequences" of one row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void packed_stats_kernel(const int64_t* __restrict__ tokens,
+                                                            const int* __restrict__ seg, int n_seg, int rows,
+                                                            int pad_idx, int mask_idx,
+                                                            float* __restrict__ scale_row,
+                                                            float* __restrict__ key_bias,
+                                                            int* __restrict__ row_pos,
+                                                            int* __restrict__ seg_npad) {
+    __shared__ int s_mask[4], s_pad[4];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int start = seg[2 * s], len = seg[2 * s + 1];
+    const int next = (s + 1 < n_seg) ? seg[2 * s + 2] : rows;
+    int n_mask = 0, n_pad = 0;
+    for (int t = tid; t < len; t += 256) {
+        const int64_t tok = tokens[start + t];
+        const bool is_pad = tok == pad_idx;
+        n_mask += tok == mask_idx;
+        n_pad += is_pad;
+        key_bias[start + t] = is_pad ? -INFINITY : 0.f;
+        row_pos[start + t] = t;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        n_mask += __shfl_xor(n_mask, o, 64);
+        n_pad += __shfl_xor(n_pad, o, 64);
+    }
+    if ((tid & 63) == 0) {
+        s_mask[tid >> 6] = n_mask;
+        s_pad[tid >> 6] = n_pad;
+    }
+    __syncthreads();
+    n_mask = s_mask[0] + s_mask[1] + s_mask[2] + s_mask[3];
+    n_pad = s_pad[0] + s_pad[1] + s_pad[2] + s_pad[3];
+    const float ratio = (float)n_mask / (float)(len - n_pad);  // esm2.py:91
+    const float den = 1.0f - ratio;                             // esm2.py:92 divisor
+    for (int t = tid; t < len; t += 256) scale_row[start + t] = den;
+    for (int m = start + len + tid; m < next; m += 256) {  // gap rows: <pad> tokens nobody attends to
+        scale_row[m] = 1.0f;
+        key_bias[m] = -INFINITY;
+        row_pos[m] = 0;
+    }
+    if (tid == 0) seg_npad[s] = n_pad;
+}
+
+hipError_t launch_packed_stats(const int64_t* tokens, const int* seg, int n_seg, int rows, int pad_idx,
+                               int mask_idx, float* scale_row, float* key_bias, int* row_pos, int* seg_npad,
+                               hipStream_t st) {
+    if (n_seg <= 0 || rows <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(packed_stats_kernel, dim3(n_seg), dim3(256), 0, st, tokens, seg, n_seg, rows, pad_idx,
+                       mask_idx, scale_row, key_bias, row_pos, seg_npad);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // learned positions of ESM-1b / ESM-1v — reference esm/model/esm1.py:133 and
 // LearnedPositionalEmbedding.forward (esm/modules.py:240-257):
 //   x[b,t,:] += embed_positions[cumsum(nonpad)[t] * nonpad[t] + pad_idx]         (one workgroup per sequence)

@@ -75,15 +75,29 @@ struct Workspace {
     size_t scale, key_bias, seq_info, keep, x, h, big, lse, ct_scratch, total;
     size_t q, k, vt;  // inside big
     int Tp;
+    size_t row_pos, tables;  // token-packed batches only
 };
 
-Workspace plan_workspace(const esmk_model* m, int B, int T, uint32_t flags) {
+// Token-packed batch (esmk_forward_packed): ONE row space of `rows` rows holding n_seg segments.  The layer
+// stack sees it as B = 1, T = rows; only three kernels know about segments (token statistics, the rotary
+// position in the q/k epilogue, the attention kernel's key range).
+struct PackedCtx {
+    int n_seg = 0, max_len = 0, n_items = 0;
+    double sum_len2 = 0;                // sum of len^2: the attention work
+    const int32_t* seg_host = nullptr;  // [n_seg][2] = (first row, length)
+};
+// query blocks of 128 rows: sum over segments of ceil(len / 128) <= rows / 128 + n_seg
+inline size_t packed_items_bound(int n_seg, int rows) { return (size_t)rows / 128 + (size_t)n_seg; }
+
+Workspace plan_workspace(const esmk_model* m, int B, int T, uint32_t flags, int packed_segs = 0) {
     Workspace w{};
     const size_t os = op_size(m->cfg.operand_dtype);
     const size_t N = (size_t)B * T, E = m->E, F = m->F, EA = m->EA, Kp = m->Kp;
-    w.Tp = (T + 63) / 64 * 64;
+    // packed: one spare (zeroed) key tile behind the rows, because a segment's last 64-key tile may start
+    // anywhere and reach past the last row
+    w.Tp = (T + 63) / 64 * 64 + (packed_segs > 0 ? 64 : 0);
     Carve c;
-    w.scale = c.take(B * 4);
+    w.scale = c.take((packed_segs > 0 ? N : (size_t)B) * 4);
     w.key_bias = c.take(N * 4);
     w.seq_info = c.take((size_t)B * 2 * 4);
     w.keep = c.take(m->cfg.num_positions > 0 ? N * 4 : 0);
@@ -103,6 +117,11 @@ Workspace plan_workspace(const esmk_model* m, int B, int T, uint32_t flags) {
     const int S = T - (m->cfg.prepend_bos ? 1 : 0) - (m->cfg.append_eos ? 1 : 0);
     w.ct_scratch =
         c.take((flags & ESMK_OUT_CONTACTS) ? (size_t)B * m->L * m->H * (size_t)(S > 0 ? S + 1 : 1) * 4 : 0);
+    if (packed_segs > 0) {
+        w.row_pos = c.take(N * 4);
+        // [seg 2 n_seg][npad n_seg][work 4 n_items]
+        w.tables = c.take(((size_t)3 * packed_segs + 4 * packed_items_bound(packed_segs, T)) * 4);
+    }
     w.total = c.off;
     return w;
 }
@@ -241,6 +260,8 @@ void esmk_destroy(esmk_model* m) {
     if (m->d_inv_freq) (void)hipFree(m->d_inv_freq);
     if (m->d_ucos) (void)hipFree(m->d_ucos);
     if (m->d_usin) (void)hipFree(m->d_usin);
+    if (m->pk_host) (void)hipHostFree(m->pk_host);
+    if (m->pk_event) (void)hipEventDestroy(m->pk_event);
     delete m;
 }
 
@@ -385,17 +406,90 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
 int esmk_workspace_bytes(const esmk_model* m, int B, int T, uint32_t out_flags, size_t* bytes) {
     if (!m || !bytes) return fail("esmk_workspace_bytes: null argument");
     if (B <= 0 || T <= 0) return fail("esmk_workspace_bytes: B and T must be positive");
+    if ((long long)B * T > ESMK_MAX_ROWS) return fail("esmk_workspace_bytes: B*T exceeds 2^24 rows");
     *bytes = plan_workspace(m, B, T, out_flags).total;
     return 0;
 }
+
+static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* tokens_dev, int B, int T,
+                        const int32_t* repr_layers, int n_repr, void* const* repr_out_dev,
+                        uint32_t out_flags, void* logits_out_dev, void* attn_out_dev,
+                        void* contacts_out_dev, void* workspace_dev, size_t workspace_bytes,
+                        void* stream, const PackedCtx* pc);
 
 int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_dev, int B, int T,
                  const int32_t* repr_layers, int n_repr, void* const* repr_out_dev,
                  uint32_t out_flags, void* logits_out_dev, void* attn_out_dev,
                  void* contacts_out_dev, void* workspace_dev, size_t workspace_bytes,
                  void* stream) {
+    return forward_impl(m, packed_dev, tokens_dev, B, T, repr_layers, n_repr, repr_out_dev, out_flags,
+                        logits_out_dev, attn_out_dev, contacts_out_dev, workspace_dev, workspace_bytes, stream,
+                        nullptr);
+}
+
+// ---- token-packed batches (no compute on padding) --------------------------------------
+static int check_segments(const char* who, const esmk_model* m, const int32_t* seg, int n_seg, int rows,
+                          PackedCtx* pc) {
+    const std::string w(who);
+    if (!m || !seg) return fail(w + ": null argument");
+    if (m->is_msa) return fail(w + ": not an ESM-2 handle");
+    if (m->cfg.num_positions > 0) return fail(w + ": learned-position models (ESM-1b) take padded batches");
+    if (m->D == 128) return fail(w + ": head_dim 128 takes padded batches");
+    if (n_seg <= 0 || rows <= 0) return fail(w + ": n_seg and rows must be positive");
+    if (rows % 64 != 0) return fail(w + ": rows must be a multiple of 64");
+    if (rows > ESMK_MAX_ROWS) return fail(w + ": rows exceed 2^24");
+    long long end = 0;
+    int max_len = 0;
+    size_t items = 0;
+    for (int s = 0; s < n_seg; ++s) {
+        const int start = seg[2 * s], len = seg[2 * s + 1];
+        if (len <= 0) return fail(w + ": empty segment");
+        if (start % 16 != 0) return fail(w + ": segment starts must be multiples of 16");
+        if ((s == 0 && start != 0) || start < end) return fail(w + ": segments must start at row 0, ascending, disjoint");
+        end = (long long)start + len;
+        if (end > rows) return fail(w + ": segment past the last row");
+        max_len = std::max(max_len, len);
+        items += (size_t)(len + 127) / 128;
+        if (pc) pc->sum_len2 += (double)len * len;
+    }
+    if (pc) {
+        pc->n_seg = n_seg;
+        pc->max_len = max_len;
+        pc->n_items = (int)items;
+        pc->seg_host = seg;
+    }
+    return 0;
+}
+
+int esmk_packed_workspace_bytes(const esmk_model* m, int n_seg, int rows, uint32_t out_flags, size_t* bytes) {
+    if (!m || !bytes) return fail("esmk_packed_workspace_bytes: null argument");
+    if (n_seg <= 0 || rows <= 0 || rows % 64 != 0 || rows > ESMK_MAX_ROWS)
+        return fail("esmk_packed_workspace_bytes: need n_seg > 0 and 0 < rows <= 2^24, rows % 64 == 0");
+    if (out_flags & ~(uint32_t)ESMK_OUT_LOGITS) return fail("esmk_packed_workspace_bytes: only ESMK_OUT_LOGITS is available");
+    *bytes = plan_workspace(m, 1, rows, out_flags, n_seg).total;
+    return 0;
+}
+
+int esmk_forward_packed(esmk_model* m, const void* packed_dev, const int64_t* tokens_dev,
+                        const int32_t* segments_host, int n_seg, int rows, const int32_t* repr_layers,
+                        int n_repr, void* const* repr_out_dev, uint32_t out_flags, void* logits_out_dev,
+                        void* workspace_dev, size_t workspace_bytes, void* stream) {
+    PackedCtx pc;
+    if (check_segments("esmk_forward_packed", m, segments_host, n_seg, rows, &pc)) return 1;
+    if (out_flags & ~(uint32_t)ESMK_OUT_LOGITS)
+        return fail("esmk_forward_packed: attention maps and contacts take padded batches (esmk_forward)");
+    return forward_impl(m, packed_dev, tokens_dev, 1, rows, repr_layers, n_repr, repr_out_dev, out_flags,
+                        logits_out_dev, nullptr, nullptr, workspace_dev, workspace_bytes, stream, &pc);
+}
+
+static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* tokens_dev, int B, int T,
+                        const int32_t* repr_layers, int n_repr, void* const* repr_out_dev,
+                        uint32_t out_flags, void* logits_out_dev, void* attn_out_dev,
+                        void* contacts_out_dev, void* workspace_dev, size_t workspace_bytes,
+                        void* stream, const PackedCtx* pc) {
     if (!m || !packed_dev || !tokens_dev || !workspace_dev) return fail("esmk_forward: null argument");
     if (B <= 0 || T <= 0) return fail("esmk_forward: B and T must be positive");
+    if ((long long)B * T > ESMK_MAX_ROWS) return fail("esmk_forward: B*T exceeds 2^24 rows");
     if (n_repr > 0 && (!repr_layers || !repr_out_dev)) return fail("esmk_forward: null repr arrays");
     const bool want_logits = out_flags & ESMK_OUT_LOGITS;
     const bool want_contacts = out_flags & ESMK_OUT_CONTACTS;
@@ -406,7 +500,7 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
     for (int i = 0; i < n_repr; ++i)
         if (repr_layers[i] < 0 || repr_layers[i] > m->L || !repr_out_dev[i])
             return fail("esmk_forward: bad repr layer request");
-    const Workspace w = plan_workspace(m, B, T, out_flags);
+    const Workspace w = plan_workspace(m, B, T, out_flags, pc ? pc->n_seg : 0);
     if (workspace_bytes < w.total) return fail("esmk_forward: workspace too small");
 
     hipStream_t st = (hipStream_t)stream;
@@ -427,10 +521,51 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
     float* g32 = (float*)(ws + w.big);
     float* lse = want_attn ? (float*)(ws + w.lse) : nullptr;
 
+    const int T_rope = pc ? pc->max_len : T;  // longest run of positions
     if (m->cfg.no_rope) {
-        if (ensure_unit_rope(m, T, st)) return 1;
-    } else if (ensure_rope(m, T, st)) {
+        if (ensure_unit_rope(m, T_rope, st)) return 1;
+    } else if (ensure_rope(m, T_rope, st)) {
         return 1;
+    }
+    // token-packed batch: segment table, <pad> counts and the attention work list live behind the workspace
+    int* row_pos = nullptr;
+    AttnSegs segs;
+    if (pc) {
+        int* tab = (int*)(ws + w.tables);
+        const size_t n_int = (size_t)3 * pc->n_seg + (size_t)4 * pc->n_items;
+        if (m->pk_event) ESMK_TRY(hipEventSynchronize(m->pk_event));  // the previous upload has read the staging
+        else ESMK_TRY(hipEventCreateWithFlags(&m->pk_event, hipEventDisableTiming));
+        if (m->pk_host_cap < n_int) {
+            if (m->pk_host) ESMK_TRY(hipHostFree(m->pk_host));
+            m->pk_host = nullptr;
+            m->pk_host_cap = 0;
+            ESMK_TRY(hipHostMalloc((void**)&m->pk_host, 2 * n_int * 4, hipHostMallocDefault));
+            m->pk_host_cap = 2 * n_int;
+        }
+        int32_t* hostv = m->pk_host;
+        memcpy(hostv, pc->seg_host, (size_t)2 * pc->n_seg * 4);
+        memset(hostv + (size_t)2 * pc->n_seg, 0, (size_t)pc->n_seg * 4);
+        // query blocks, longest segments first: the tail of the grid is made of short work items
+        std::vector<int> order(pc->n_seg);
+        for (int s = 0; s < pc->n_seg; ++s) order[s] = s;
+        std::stable_sort(order.begin(), order.end(),
+                         [&](int a, int b) { return pc->seg_host[2 * a + 1] > pc->seg_host[2 * b + 1]; });
+        int32_t* wk = hostv + (size_t)3 * pc->n_seg;
+        for (int s : order) {
+            const int start = pc->seg_host[2 * s], len = pc->seg_host[2 * s + 1];
+            for (int q0 = 0; q0 < len; q0 += 128) {
+                wk[0] = start;
+                wk[1] = len;
+                wk[2] = q0;
+                wk[3] = s;
+                wk += 4;
+            }
+        }
+        ESMK_TRY(hipMemcpyAsync(tab, hostv, n_int * 4, hipMemcpyHostToDevice, st));
+        ESMK_TRY(hipEventRecord(m->pk_event, st));
+        row_pos = (int*)(ws + w.row_pos);
+        segs.npad = tab + (size_t)2 * pc->n_seg;
+        segs.work = tab + (size_t)3 * pc->n_seg;
     }
 
     const double NE = (double)N * E;
@@ -470,10 +605,18 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         ProfScope ps(m, st, PC_EMBED, 0, (double)N * 8 + 4 * NE);
         const bool esm1b = m->cfg.num_positions > 0;
         float* keep = esm1b ? (float*)(ws + w.keep) : nullptr;
-        ESMK_TRY(launch_seq_stats(tokens_dev, B, T, m->cfg.pad_idx, m->cfg.mask_idx,
-                                  m->cfg.token_dropout, scale, key_bias, seq_info, st, keep));
-        ESMK_TRY(launch_embed(tokens_dev, (const float*)(pk + m->embed_f32), scale, x, B, T, E, m->V,
-                              m->cfg.pad_idx, m->cfg.mask_idx, m->cfg.token_dropout, st));
+        if (pc) {
+            ESMK_TRY(launch_packed_stats(tokens_dev, (const int*)(ws + w.tables), pc->n_seg, T, m->cfg.pad_idx,
+                                         m->cfg.mask_idx, scale, key_bias, row_pos, (int*)segs.npad, st));
+            // the token-dropout divisor is per row: "sequences" of one token
+            ESMK_TRY(launch_embed(tokens_dev, (const float*)(pk + m->embed_f32), scale, x, T, 1, E, m->V,
+                                  m->cfg.pad_idx, m->cfg.mask_idx, m->cfg.token_dropout, st));
+        } else {
+            ESMK_TRY(launch_seq_stats(tokens_dev, B, T, m->cfg.pad_idx, m->cfg.mask_idx,
+                                      m->cfg.token_dropout, scale, key_bias, seq_info, st, keep));
+            ESMK_TRY(launch_embed(tokens_dev, (const float*)(pk + m->embed_f32), scale, x, B, T, E, m->V,
+                                  m->cfg.pad_idx, m->cfg.mask_idx, m->cfg.token_dropout, st));
+        }
         if (esm1b) {
             // esm1.py:133-139: + learned positions, emb_layer_norm_before, padded positions zeroed
             if (T > m->cfg.num_positions - m->cfg.pad_idx - 1)
@@ -497,7 +640,9 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         const LayerOff& o = m->layer[l];
         // keys in [T,Tp) of V^T get probability exactly 0 but must be finite; the region is
         // shared with the FFN intermediate, so it is cleared every layer (odd T only).
-        if (w.Tp != T) ESMK_TRY(hipMemsetAsync(vt, 0, (size_t)B * EA * w.Tp * os, st));
+        if (pc)  // only the spare key tile: every row below it is a computed (finite) row
+            ESMK_TRY(hipMemset2DAsync((char*)vt + (size_t)T * os, (size_t)w.Tp * os, 0, 64 * os, (size_t)EA, st));
+        else if (w.Tp != T) ESMK_TRY(hipMemsetAsync(vt, 0, (size_t)B * EA * w.Tp * os, st));
         if (lnorm(x, o.ln1g, o.ln1b, h, nullptr)) return 1;
         g = GemmArgs();
         g.A = h;
@@ -517,15 +662,18 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
         g.Tp = w.Tp;
         g.scaling = 1.0f / sqrtf((float)m->D);
         g.head_dim = m->D == 128 ? 128 : 64;
+        g.row_pos = row_pos;
         if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;  // q, k: weight rows [0,2EA)
+        g.row_pos = nullptr;
         g.W = pk + o.wqkv + (size_t)2 * EA * Kp * os;           // v: weight rows [2EA,3EA)
         g.bias = (const float*)(pk + o.bqkv) + 2 * EA;
         g.N = EA;
         if (gemm(PC_GEMM_QKV, g, EPI_V_T, os)) return 1;
         {
             // 4 T d flop per (query, head) pair: QK^T and PV; q,k,v read + ctx written
-            ProfScope ps(m, st, PC_ATTENTION, 4.0 * N * (double)T * E, 4 * NE * os);
-            if (m->D == 128) ESMK_TRY(launch_attention128(q, k, vt, key_bias, seq_info, h, lse, B, H, T, w.Tp, op, st));
+            ProfScope ps(m, st, PC_ATTENTION, pc ? 4.0 * pc->sum_len2 * E : 4.0 * N * (double)T * E, 4 * NE * os);
+            if (pc) ESMK_TRY(launch_attention_packed(q, k, vt, key_bias, h, H, T, w.Tp, segs, pc->n_items, op, st));
+            else if (m->D == 128) ESMK_TRY(launch_attention128(q, k, vt, key_bias, seq_info, h, lse, B, H, T, w.Tp, op, st));
             else ESMK_TRY(launch_attention(q, k, vt, key_bias, seq_info, h, lse, B, H, T, w.Tp, op, st));
         }
         if (want_attn) {

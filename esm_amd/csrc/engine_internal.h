@@ -41,6 +41,10 @@ struct MsaLayerOff {
 
 }  // namespace esmk_host
 
+// row counts travel as int through the kernels (row * ld products are widened to 64 bit); 2^24 rows of fp32
+// residual already exceed one GPU's HBM for every supported width, so this is a guard, not a limit in practice
+#define ESMK_MAX_ROWS (1LL << 24)
+
 #define ESMK_TRY(expr)                                             \
     do {                                                           \
         hipError_t _e = (expr);                                    \
@@ -70,6 +74,10 @@ struct esmk_model {
     };
     bool prof_on = false;
     std::vector<ProfRec> prof;
+    // esmk_forward_packed: pinned host staging of the segment / work tables; pk_event = its last upload
+    int32_t* pk_host = nullptr;
+    size_t pk_host_cap = 0;
+    hipEvent_t pk_event = nullptr;
     // MSA Transformer (esmk_msa_create)
     bool is_msa = false;
     int npos = 0, has_msa_pos = 0;

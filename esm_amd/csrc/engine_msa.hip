@@ -147,6 +147,7 @@ int esmk_msa_create(const esmk_msa_config* cfg, esmk_model** out) {
 int esmk_msa_workspace_bytes(const esmk_model* m, int B, int R, int C, uint32_t out_flags, size_t* bytes) {
     if (!m || !bytes || !m->is_msa) return fail("esmk_msa_workspace_bytes: not an MSA model handle");
     if (B <= 0 || R <= 0 || C <= 0) return fail("esmk_msa_workspace_bytes: B, R, C must be positive");
+    if ((long long)B * R * C > ESMK_MAX_ROWS) return fail("esmk_msa_workspace_bytes: B*R*C exceeds 2^24 rows");
     *bytes = plan_msa_workspace(m, B, R, C, out_flags).total;
     return 0;
 }
@@ -158,6 +159,7 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
     if (!m || !m->is_msa) return fail("esmk_msa_forward: not an MSA model handle");
     if (!packed_dev || !tokens_dev || !workspace_dev) return fail("esmk_msa_forward: null argument");
     if (B <= 0 || R <= 0 || C <= 0) return fail("esmk_msa_forward: B, R, C must be positive");
+    if ((long long)B * R * C > ESMK_MAX_ROWS) return fail("esmk_msa_forward: B*R*C exceeds 2^24 rows");
     if (R > 1024 && m->has_msa_pos)
         return fail("esmk_msa_forward: MSA position embedding covers a depth of 1024 alignments");  // msa_transformer.py:160-164
     if (C > 1024) return fail("esmk_msa_forward: more than 1024 columns are not supported");

@@ -573,6 +573,7 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
     }();
     if (!env_old && !p.force_old && !p.force_generic && gemm8_supports(p, epi))
         return launch_gemm8(p, epi, operand_dtype, st);
+    if (gemm8_generalised(p, epi)) return hipErrorInvalidValue;  // the tile kernels below only know dense calls
     if (operand_dtype == ESMK_DT_F16) return dispatch<_Float16>(p, epi, st);
     if (operand_dtype == ESMK_DT_BF16) return dispatch<__bf16>(p, epi, st);
     return hipErrorInvalidValue;

@@ -195,7 +195,7 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = min(m_base + 32 * i + lm, p.M - 1);
-            const int t = m % p.T;
+            const int t = (GEN && p.row_pos != nullptr) ? p.row_pos[m] : m % p.T;
             // MSA row attention zeroes q at padded positions (axial_attention.py:85-88)
             const float keep = (GEN && which == 0 && p.row_keep != nullptr) ? p.row_keep[m] : 1.0f;
 #pragma unroll
@@ -746,6 +746,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
 // --------------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------------
+// generalised addressing requested?  (MSA Transformer calls, batched / strided / remapped GEMMs, packed batches)
+bool gemm8_generalised(const GemmArgs& p, int epi) {
+    return p.a_row_bytes || p.w_row_bytes || p.a_kt_bytes || p.w_kt_bytes || p.batch > 1 || p.n_valid > 0 ||
+           p.ldc > 0 || p.row_keep != nullptr || p.vt_rows > 0 || p.rowmap_R > 0 || epi == EPI_MSA_CTX ||
+           p.head_dim != 64 || p.row_pos != nullptr;
+}
+
 static int num_workgroups() {
     static int n = 0;
     if (n == 0) {
@@ -826,9 +833,7 @@ static hipError_t dispatch8(const GemmArgs& p, int epi, hipStream_t st) {
         return 0;
     }();
     // generalised addressing requested?  (MSA Transformer calls, batched / strided / remapped GEMMs)
-    const bool gen = p.a_row_bytes || p.w_row_bytes || p.a_kt_bytes || p.w_kt_bytes || p.batch > 1 || p.n_valid > 0 ||
-                     p.ldc > 0 || p.row_keep != nullptr || p.vt_rows > 0 || p.rowmap_R > 0 || epi == EPI_MSA_CTX ||
-                     p.head_dim != 64;
+    const bool gen = gemm8_generalised(p, epi);
 #define ESMK_CASES(SC, DB, PFD)                                                          \
     switch (epi) {                                                                       \
         case EPI_STORE_T: return launch8<T, EPI_STORE_T, SC, DB, PFD>(p, st);            \

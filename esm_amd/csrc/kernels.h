@@ -48,11 +48,13 @@ struct GemmArgs {
     int rowmap_R = 0, rowmap_C = 0;   // EPI_RESID_F32: GEMM row (b,c,r) is added to output row (b,r,c)
     int ctx_R = 0, ctx_C = 0;         // EPI_MSA_CTX geometry
     int head_dim = 64;                // EPI_QKV_ROPE / EPI_V_T: 64, or 128 (two 64-column slices per head)
+    const int* row_pos = nullptr;     // EPI_QKV_ROPE: rotary position of row m (token-packed batches; default m % T)
 };
 
 hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st);
 // gemm8.hip: persistent ping-pong kernel (K % 64 == 0, N % 8 == 0); launch_gemm prefers it
 bool gemm8_supports(const GemmArgs& p, int epi);
+bool gemm8_generalised(const GemmArgs& p, int epi);  // uses fields only the persistent kernel implements
 hipError_t launch_gemm8(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st);
 // measurement hook: per-tile s_memtime stamps of workgroup-leader lanes ([workgroup][tile & 31][4])
 void gemm8_set_timing(unsigned long long* dev_buf);
@@ -108,7 +110,24 @@ hipError_t launch_contacts(const float* attn, const int64_t* tokens, const float
                            const float* b, float* scratch, float* out, int B, int C, int T,
                            int eos_idx, int prepend_bos, int append_eos, hipStream_t st);
 
+// token-packed batch (esmk_forward_packed): per-row bookkeeping of the packed row space.  Segment s occupies
+// rows [seg[2s], seg[2s] + seg[2s+1]); rows outside every segment are gaps.
+//   scale_row[m] = 1 - n_mask/len of m's segment (esm2.py:91-92; 1 in gaps), key_bias[m] = 0 / -inf (pad, gap),
+//   row_pos[m] = m - segment start (0 in gaps), seg_npad[s] = number of <pad> tokens inside segment s
+hipError_t launch_packed_stats(const int64_t* tokens, const int* seg, int n_seg, int rows, int pad_idx,
+                               int mask_idx, float* scale_row, float* key_bias, int* row_pos, int* seg_npad,
+                               hipStream_t st);
+
 // ---- attention.hip ---------------------------------------------------------------------
+// query-block work list of a token-packed batch: work[4i..4i+3] = (first row of the segment, segment length,
+// first query of block i relative to the segment, segment index); npad[s] = <pad> tokens inside segment s
+struct AttnSegs {
+    const int* work = nullptr;
+    const int* npad = nullptr;
+};
+hipError_t launch_attention_packed(const void* q, const void* k, const void* vt, const float* key_bias, void* ctx,
+                                   int H, int rows, int Tp, AttnSegs segs, int n_items, int operand_dtype,
+                                   hipStream_t st);
 hipError_t launch_attention(const void* q, const void* k, const void* vt, const float* key_bias,
                             const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
                             int operand_dtype, hipStream_t st);

@@ -136,6 +136,15 @@ class _Engine:
         except Exception:
             pass
 
+    def workspace_for_packed(self, n_seg, rows, flags):
+        N = self.N
+        need = ctypes.c_size_t()
+        N.check(N.lib.esmk_packed_workspace_bytes(self.handle, n_seg, rows, flags, ctypes.byref(need)))
+        if self.workspace is None or self.workspace.numel() < need.value:
+            self.workspace = None
+            self.workspace = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        return self.workspace
+
     def sync_weights(self, model):
         """Re-pack the parameter image when any parameter storage or version changed
         (``.cuda()``, ``.half()``, ``load_state_dict``, in-place edits)."""
@@ -268,6 +277,65 @@ class ESM2(nn.Module):
             if return_contacts:
                 result["contacts"] = cast(contacts)
         return result
+
+    # ------------------------------------------------------------------------------------------
+    # token-packed batches: no compute on padding (include/esmk.h, esmk_forward_packed)
+    @property
+    def supports_varlen(self):
+        """Token-packed batches exist for rotary models with head_dim <= 64 (every ESM-2 but the 15B)."""
+        return int(getattr(self, "_engine_num_positions", 0)) == 0 and self.embed_dim // self.attention_heads <= 64
+
+    def forward_varlen(self, tokens, repr_layers=[], lengths=None, min_saving=0.08, unpack=True):
+        """Same results as ``forward(tokens, repr_layers)`` on the non-pad positions of a RIGHT-padded batch
+        (what ``BatchConverter`` yields, reference esm/data.py:262-297), but the sequences are laid back to back
+        in one row space and the engine does no work on padding.  Pad positions of the returned tensors are zero
+        (the reference leaves the values the pad rows happened to compute there).
+
+        tokens   [B,T] int64, CPU or device; from a CPU tensor the lengths are read without a device sync
+        lengths  optional per-row token counts (incl. <cls>/<eos>); default: up to the last non-pad token
+        min_saving  fall back to ``forward`` when packing saves less than this fraction of the rows
+                    (None: always pack)
+        unpack   False: return the packed tensors ([rows, .]) plus ``segments`` ([B,2] first row, length)
+
+        Attention maps and contacts are per-sequence [T,T] objects: use ``forward`` for those."""
+        assert tokens.ndim == 2
+        from . import _native as N
+        from .packing import pack_plan
+
+        w = self.embed_tokens.weight
+        if not w.is_cuda:
+            raise RuntimeError("esm_amd.ESM2 runs only on an MI355X (ROCm) device; the engine has no CPU fallback")
+        dev = w.device
+        B, T = tokens.shape
+        L, E, V = self.num_layers, self.embed_dim, self.alphabet_size
+        plan = pack_plan(tokens, self.padding_idx, lengths)
+        if unpack and min_saving is not None and plan.rows > (1.0 - min_saving) * B * T:
+            return self.forward(tokens.to(dev), repr_layers=repr_layers)
+        repr_set = sorted({int(i) for i in repr_layers if 0 <= int(i) <= L})
+        with torch.cuda.device(dev):
+            eng = self._get_engine(dev)
+            eng.sync_weights(self)
+            idx, keep = plan.index(dev)
+            flat = plan.pack(tokens, self.padding_idx, idx)
+            f32 = dict(dtype=torch.float32, device=dev)
+            logits = torch.empty((plan.rows, V), **f32)
+            reps = [torch.empty((plan.rows, E), **f32) for _ in repr_set]
+            ws = eng.workspace_for_packed(B, plan.rows, N.OUT_LOGITS)
+            seg = plan.segments  # int32 [B,2], CPU, contiguous
+            layers_arr = (ctypes.c_int32 * max(1, len(repr_set)))(*repr_set)
+            outs_arr = (ctypes.c_void_p * max(1, len(repr_set)))(*[r.data_ptr() for r in reps])
+            N.check(N.lib.esmk_forward_packed(
+                eng.handle, N.ptr(eng.packed), N.ptr(flat),
+                ctypes.cast(seg.data_ptr(), ctypes.POINTER(ctypes.c_int32)), B, plan.rows,
+                layers_arr, len(repr_set), outs_arr, N.OUT_LOGITS, N.ptr(logits), N.ptr(ws), ws.numel(),
+                N.cur_stream()))
+        out_dt = w.dtype
+        cast = (lambda t: t) if out_dt == torch.float32 else (lambda t: t.to(out_dt))
+        if not unpack:
+            return {"logits": cast(logits), "representations": {l: cast(r) for l, r in zip(repr_set, reps)},
+                    "segments": seg}
+        un = lambda t: plan.unpack(t, idx, keep)
+        return {"logits": cast(un(logits)), "representations": {l: cast(un(r)) for l, r in zip(repr_set, reps)}}
 
     def profile_begin(self):
         """Arm per-kernel-class HIP-event timing of the following forward calls (bench.py)."""

@@ -158,7 +158,8 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
             truncation_seq_length: int = 1022, device: Optional[torch.device] = None,
             gather_mean: bool = True, log: Callable[[str], None] = print):
     """Run the sharded extraction.  ``embed_fn(tokens, repr_layers, return_contacts)`` is the model
-    forward (``ESM2.__call__`` in production).  Returns ``{layer: [n_sequences, E] mean embeddings}``
+    forward (``ESM2.__call__`` / ``ESM2.forward_varlen`` in production; an ``embed_fn.wants_lengths = True``
+    attribute asks for the extra keyword ``lengths`` = per-row token counts, taken from the host copy).  Returns ``{layer: [n_sequences, E] mean embeddings}``
     in dataset order when ``gather_mean`` (every rank gets the full matrix), else ``{}``."""
     dist, rank, world = _dist_info()
     assert all(-(num_layers + 1) <= i <= num_layers for i in repr_layers)
@@ -221,9 +222,12 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
             ids = batches[bid]
             labels, strs, toks = convert([dataset[i] for i in ids])
             log(f"[rank {rank}] batch {n_done + 1}/{len(plan[rank])}: {toks.size(0)} sequences x {toks.size(1)} tokens")
+            kw = {}
+            if getattr(embed_fn, "wants_lengths", False):  # token counts, read before the tokens leave the host
+                kw["lengths"] = (toks.ne(alphabet.padding_idx) * torch.arange(1, toks.size(1) + 1)).amax(dim=1)
             if device is not None:
                 toks = toks.to(device=device, non_blocking=True)
-            out = embed_fn(toks, layers, return_contacts)
+            out = embed_fn(toks, layers, return_contacts, **kw)
             reps = {l: t for l, t in out["representations"].items()}
             contacts = out["contacts"] if return_contacts else None
             means_dev = batch_means(reps, strs)
@@ -282,6 +286,8 @@ def create_parser():
     p.add_argument("--repr_layers", type=int, default=[-1], nargs="+")
     p.add_argument("--include", type=str, nargs="+", choices=["mean", "per_tok", "bos", "contacts"], required=True)
     p.add_argument("--truncation_seq_length", type=int, default=1022)
+    p.add_argument("--no_varlen", action="store_true",
+                   help="always run padded batches (default: token-packed batches whenever they save >= 8 %% of the rows)")
     p.add_argument("--mean_matrix", type=pathlib.Path, default=None,
                    help="rank 0 also writes {layer: [n_sequences, E]} gathered mean embeddings to this file")
     return p
@@ -310,8 +316,14 @@ def main(argv=None):
     if rank == 0:
         print(f"Read {args.fasta_file} with {len(dataset)} sequences; {world} rank(s)")
 
-    def embed_fn(toks, layers, return_contacts):
+    varlen = (not args.no_varlen) and getattr(model, "supports_varlen", False)
+
+    def embed_fn(toks, layers, return_contacts, lengths=None):
+        if varlen and not return_contacts:  # no compute on padding (contact maps are per-sequence [T,T]: padded path)
+            return model.forward_varlen(toks, repr_layers=layers, lengths=lengths)
         return model(toks, repr_layers=layers, return_contacts=return_contacts)
+
+    embed_fn.wants_lengths = True
 
     means = extract(dataset, alphabet, embed_fn, model.num_layers, model.embed_dim, args.repr_layers, args.include,
                     output_dir=args.output_dir, toks_per_batch=args.toks_per_batch,

@@ -102,6 +102,25 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
                  void* contacts_out_dev, void* workspace_dev, size_t workspace_bytes,
                  void* stream);
 
+/* ---- token-packed batches: the same forward without compute on padding -------------
+ * The reference pads every batch to its longest member (esm/data.py:269-277) and ESM2.forward computes the
+ * pad rows (esm2.py:94-95 only zeroes them at the input).  Here the caller lays the sequences of a batch back
+ * to back in ONE row space of `rows` rows (rows % 64 == 0): segment s occupies rows
+ * [segments_host[2s], segments_host[2s] + segments_host[2s+1]); segment 0 starts at row 0, starts are
+ * ascending multiples of 16, rows between segments ("gaps") hold pad_idx.  Every token attends to its own
+ * segment only, rotary positions restart at each segment, the token-dropout ratio (esm2.py:86-92) is per
+ * segment: rows of a segment carry exactly the values esmk_forward gives that sequence alone.
+ *   tokens_dev      int64 [rows]
+ *   segments_host   int32 [n_seg][2] on the HOST (first row, length incl. <cls>/<eos>)
+ *   repr_out_dev[i] fp32 [rows,E]; logits_out_dev fp32 [rows,V] (iff ESMK_OUT_LOGITS); gap rows are undefined
+ * Attention maps / contacts are [T,T] per sequence and stay with esmk_forward; so do ESM-1b (learned
+ * positions) and head_dim 128 for now: those requests fail with an error. */
+int esmk_packed_workspace_bytes(const esmk_model* m, int n_seg, int rows, uint32_t out_flags, size_t* bytes);
+int esmk_forward_packed(esmk_model* m, const void* packed_dev, const int64_t* tokens_dev,
+                        const int32_t* segments_host, int n_seg, int rows, const int32_t* repr_layers,
+                        int n_repr, void* const* repr_out_dev, uint32_t out_flags, void* logits_out_dev,
+                        void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* ---- MSA Transformer (reference esm/model/msa_transformer.py:20-238, esm/axial_attention.py) -------- */
 
 /* Constructor arguments of MSATransformer (msa_transformer.py:88-144) + alphabet ids. */

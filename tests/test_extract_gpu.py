@@ -15,7 +15,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_extract_cli_matches_oracle(tmp_path):
+# toks_per_batch 300: small batches with little padding (padded path); 1300: one batch of all five sequences,
+# run token-packed (default) and padded (--no_varlen)
+@pytest.mark.parametrize("tpb,extra", [("300", []), ("1300", []), ("1300", ["--no_varlen"])],
+                         ids=["small_batches", "one_batch_packed", "one_batch_padded"])
+def test_extract_cli_matches_oracle(tmp_path, tpb, extra):
     L, E, H = 3, 320, 20  # esm2_t6_8M width (head_dim 16), 3 layers
     ckpt = write_esm2_checkpoint(str(tmp_path), "esm2_synth_8M", L, E, H, seed=5)
     g = torch.Generator().manual_seed(3)
@@ -27,8 +31,8 @@ def test_extract_cli_matches_oracle(tmp_path):
     out_dir = tmp_path / "out"
     env = dict(os.environ, PYTHONPATH=ROOT, TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD="1")
     subprocess.run([sys.executable, "-m", "esm_amd.extract", ckpt, str(fasta), str(out_dir), "--repr_layers", "-1", "0",
-                    "--include", "mean", "per_tok", "bos", "--toks_per_batch", "300", "--mean_matrix",
-                    str(tmp_path / "means.pt")], check=True, env=env, cwd=ROOT, timeout=600)
+                    "--include", "mean", "per_tok", "bos", "--toks_per_batch", tpb, "--mean_matrix",
+                    str(tmp_path / "means.pt")] + extra, check=True, env=env, cwd=ROOT, timeout=600)
     sd = synth_esm2_state_dict(L, E, H, seed=5)
     from esm_amd import Alphabet
 

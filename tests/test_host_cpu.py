@@ -142,3 +142,23 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(_native.lib, name)
     assert b"gfx950" in _native.lib.esmk_version()
+
+
+def test_pack_plan_layout():
+    """Host side of token-packed batches (esm_amd/packing.py): segment starts on multiples of 16, the row count a
+    multiple of 128, pack / unpack are inverse on the non-pad positions."""
+    from esm_amd.packing import pack_plan
+
+    toks = torch.tensor([[0, 5, 6, 2, 1, 1], [0, 5, 2, 1, 1, 1], [0, 4, 1, 4, 4, 2]])  # row 2: interior <pad>
+    plan = pack_plan(toks, 1)
+    assert plan.lengths.tolist() == [4, 3, 6] and plan.rows == 128
+    assert plan.segments.tolist() == [[0, 4], [16, 3], [32, 6]] and plan.segments.dtype == torch.int32
+    idx, keep = plan.index("cpu")
+    flat = plan.pack(toks, 1, idx)
+    assert flat.shape == (128,)
+    assert flat[:4].tolist() == [0, 5, 6, 2] and flat[16:19].tolist() == [0, 5, 2] and flat[32:38].tolist() == [0, 4, 1, 4, 4, 2]
+    assert int(flat.ne(1).sum()) == int(toks.ne(1).sum())
+    back = plan.unpack(flat.unsqueeze(1).float(), idx, keep).squeeze(-1).long()
+    assert torch.equal(keep, torch.arange(6).unsqueeze(0) < plan.lengths.unsqueeze(1))
+    assert torch.equal(back[keep], toks[keep]) and int(back[~keep].abs().sum()) == 0
+    assert pack_plan(toks, 1, lengths=[6, 6, 6]).segments.tolist() == [[0, 6], [16, 6], [32, 6]]

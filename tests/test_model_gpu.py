@@ -234,6 +234,20 @@ def test_degenerate_lengths():
         assert rel_err(out["logits"].cpu(), ref["logits"], nonpad) < REL_SMALL
 
 
+def test_row_guard_fails_loudly():
+    """B*T beyond the engine's row limit is refused with an error (never a silent wrap of int row indices)."""
+    import ctypes
+
+    from esm_amd import _native as N
+
+    model, _ = build(1, 128, 2, seed=3)
+    model(torch.tensor([[0, 5, 2]]).cuda())  # creates the engine
+    need = ctypes.c_size_t()
+    rc = N.lib.esmk_workspace_bytes(model._engine.handle, 1 << 13, 1 << 12, 0, ctypes.byref(need))
+    assert rc != 0 and b"2^24" in N.lib.esmk_last_error()
+    assert N.lib.esmk_workspace_bytes(model._engine.handle, 1 << 12, 1 << 12, 0, ctypes.byref(need)) == 0
+
+
 def test_properties_full_length():
     """Size-independent properties at L=1022 with the 650M dimensions (no oracle needed):
     run-to-run determinism, batch-composition invariance (bit exact) and padding invariance."""
