@@ -30,7 +30,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
     const float* __restrict__ key_bias, const int* __restrict__ seq_info, T* __restrict__ ctx,
-    float* __restrict__ lse, int H, int BH, int nq, int Tlen, int Tp) {
+    float* __restrict__ lse, int H, int BH, int nq, int Tlen, int Tp, AttnSegs segs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V8 = typename Op<T>::v8;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -52,11 +52,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(
         }
     }
     const int b = bh / H, head = bh - b * H;
-    const int q0 = qblk * 128 + wave * 32;
+    // token-packed batches: query block qblk is a work item of one segment (see attention.hip)
+    int row0 = 0, Tseg = Tlen, qrel = qblk * 128;
+    bool seg_pad = false;
+    if (segs.work != nullptr) {
+        row0 = __builtin_amdgcn_readfirstlane(segs.work[4 * qblk]);
+        Tseg = __builtin_amdgcn_readfirstlane(segs.work[4 * qblk + 1]);
+        qrel = __builtin_amdgcn_readfirstlane(segs.work[4 * qblk + 2]);
+        seg_pad = segs.npad[__builtin_amdgcn_readfirstlane(segs.work[4 * qblk + 3])] > 0;
+    }
+    const int q0 = qrel + wave * 32;
+    const size_t rbase = (size_t)bh * Tlen + row0;
 
-    int kv_end = Tlen;
-    bool use_mask = (Tlen & 63) != 0;
-    if (key_bias != nullptr) {
+    int kv_end = Tseg;
+    bool use_mask = (Tseg & 63) != 0;
+    if (segs.work != nullptr) {
+        if (seg_pad) use_mask = true;
+        else key_bias = nullptr;
+    } else if (key_bias != nullptr) {
         if (seq_info != nullptr) {
             if (seq_info[2 * b] > 0) {
                 use_mask = true;
@@ -68,14 +81,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(
     }
     const int ntiles = (kv_end + 63) >> 6;
 
-    const T* kb = k + (size_t)bh * Tlen * HD;
-    const T* vb = vt + (size_t)bh * HD * Tp;
+    const T* kb = k + rbase * HD;
+    const T* vb = vt + (size_t)bh * HD * Tp + row0;
 
     // Q fragments: Q[q0 + lm][16 ks + 8 h .. +7], ks = 0..7
     V8 qf[8];
     {
-        const int qr = min(q0 + lm, Tlen - 1);
-        const T* qp = q + ((size_t)bh * Tlen + qr) * HD + 8 * h;
+        const int qr = min(q0 + lm, Tseg - 1);
+        const T* qp = q + (rbase + qr) * HD + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qp + 16 * ks);
     }
@@ -98,14 +111,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(
         const int k0 = kt * 64;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int kr = min(k0 + krow[j], Tlen - 1);
+            const int kr = min(k0 + krow[j], Tseg - 1);
             glds16(gk[j] + (size_t)kr * HD, base + (j * 256 + wave * 64) * 16);
             glds16(gv[j] + k0, base + K_TILE + (j * 256 + wave * 64) * 16);
         }
         if (use_mask && tid < 64) {
             const int key = k0 + tid;
             float bv = -INFINITY;
-            if (key < Tlen) bv = key_bias ? key_bias[(size_t)b * Tlen + key] : 0.f;
+            if (key < Tseg) bv = key_bias ? key_bias[(size_t)b * Tlen + row0 + key] : 0.f;
             reinterpret_cast<float*>(base + K_TILE + V_TILE)[tid] = bv;
         }
     };
@@ -214,22 +227,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(
             for (int e = 0; e < 4; ++e) pk[e] = Op<T>::from(o[d][4 * g + e] * inv);
             *reinterpret_cast<V4*>(wl + lm * 256 + (((4 * d + g) ^ (lm & 15)) << 4) + 8 * h) = pk;
         }
-    T* dst = ctx + ((size_t)b * Tlen) * ((size_t)H * HD) + head * HD;
+    T* dst = ctx + ((size_t)b * Tlen + row0) * ((size_t)H * HD) + head * HD;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int pc = it * 64 + lane;
         const int r = pc >> 4, c = pc & 15;
         const V8 v = *reinterpret_cast<const V8*>(wl + r * 256 + ((c ^ (r & 15)) << 4));
-        if (q0 + r < Tlen) *reinterpret_cast<V8*>(dst + (size_t)(q0 + r) * ((size_t)H * HD) + c * 8) = v;
+        if (q0 + r < Tseg) *reinterpret_cast<V8*>(dst + (size_t)(q0 + r) * ((size_t)H * HD) + c * 8) = v;
     }
     const int qrow = q0 + lm;
-    if (lse != nullptr && h == 0 && qrow < Tlen) lse[(size_t)bh * Tlen + qrow] = m2 * (1.0f / LOG2E_) + logf(ltot);
+    if (lse != nullptr && h == 0 && qrow < Tseg) lse[rbase + qrow] = m2 * (1.0f / LOG2E_) + logf(ltot);
 }
 
 template <typename TT>
 static hipError_t launch128(const void* q, const void* k, const void* vt, const float* key_bias,
                             const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
-                            hipStream_t st) {
+                            hipStream_t st, AttnSegs segs = AttnSegs(), int n_items = 0) {
     static bool attr_set = false;
     auto kern = attn_fwd128_kernel<TT>;
     if (!attr_set) {
@@ -238,10 +251,21 @@ static hipError_t launch128(const void* q, const void* k, const void* vt, const 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int nq = (T + 127) / 128;
+    const int nq = segs.work != nullptr ? n_items : (T + 127) / 128;
     hipLaunchKernelGGL(kern, dim3(nq * B * H), dim3(256), 2 * STAGE, st, (const TT*)q, (const TT*)k, (const TT*)vt,
-                       key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp);
+                       key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, segs);
     return hipGetLastError();
+}
+
+// token-packed batch (see launch_attention_packed)
+hipError_t launch_attention128_packed(const void* q, const void* k, const void* vt, const float* key_bias, void* ctx,
+                                      int H, int rows, int Tp, AttnSegs segs, int n_items, int operand_dtype,
+                                      hipStream_t st) {
+    if (segs.work == nullptr || segs.npad == nullptr || n_items <= 0 || H <= 0 || rows <= 0 || Tp < rows || (Tp & 63))
+        return hipErrorInvalidValue;
+    if (operand_dtype == ESMK_DT_BF16)
+        return launch128<__bf16>(q, k, vt, key_bias, nullptr, ctx, nullptr, 1, H, rows, Tp, st, segs, n_items);
+    return launch128<_Float16>(q, k, vt, key_bias, nullptr, ctx, nullptr, 1, H, rows, Tp, st, segs, n_items);
 }
 
 hipError_t launch_attention128(const void* q, const void* k, const void* vt, const float* key_bias,

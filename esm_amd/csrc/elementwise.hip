@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256) void packed_stats_kernel(const int64_t* __rest
                                                             float* __restrict__ scale_row,
                                                             float* __restrict__ key_bias,
                                                             int* __restrict__ row_pos,
-                                                            int* __restrict__ seg_npad) {
+                                                            int* __restrict__ seg_npad,
+                                                            float* __restrict__ keep) {
     __shared__ int s_mask[4], s_pad[4];
     const int s = blockIdx.x, tid = threadIdx.x;
     const int start = seg[2 * s], len = seg[2 * s + 1];
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void packed_stats_kernel(const int64_t* __rest
         n_pad += is_pad;
         key_bias[start + t] = is_pad ? -INFINITY : 0.f;
         row_pos[start + t] = t;
+        if (keep != nullptr) keep[start + t] = is_pad ? 0.f : 1.f;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -112,16 +114,36 @@ __global__ __launch_bounds__(256) void packed_stats_kernel(const int64_t* __rest
         scale_row[m] = 1.0f;
         key_bias[m] = -INFINITY;
         row_pos[m] = 0;
+        if (keep != nullptr) keep[m] = 0.f;
     }
     if (tid == 0) seg_npad[s] = n_pad;
 }
 
 hipError_t launch_packed_stats(const int64_t* tokens, const int* seg, int n_seg, int rows, int pad_idx,
                                int mask_idx, float* scale_row, float* key_bias, int* row_pos, int* seg_npad,
-                               hipStream_t st) {
+                               hipStream_t st, float* keep) {
     if (n_seg <= 0 || rows <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(packed_stats_kernel, dim3(n_seg), dim3(256), 0, st, tokens, seg, n_seg, rows, pad_idx,
-                       mask_idx, scale_row, key_bias, row_pos, seg_npad);
+                       mask_idx, scale_row, key_bias, row_pos, seg_npad, keep);
+    return hipGetLastError();
+}
+
+// Gap rows of a token-packed batch are nobody's queries, so the attention kernel leaves their context rows
+// unwritten; they must still be FINITE, because the next layer turns them into keys / values that the last key
+// tile of the segment in front of them multiplies by probability 0.  Workgroup s clears the gap behind segment s.
+__global__ __launch_bounds__(256) void zero_gap_rows_kernel(char* __restrict__ buf, const int* __restrict__ seg,
+                                                             int n_seg, int rows, int row_bytes) {
+    const int s = blockIdx.x;
+    const int first = seg[2 * s] + seg[2 * s + 1];
+    const int next = (s + 1 < n_seg) ? seg[2 * s + 2] : rows;
+    const size_t n16 = (size_t)(next - first) * (row_bytes >> 4);
+    f32x4* dst = reinterpret_cast<f32x4*>(buf + (size_t)first * row_bytes);
+    for (size_t i = threadIdx.x; i < n16; i += 256) dst[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+hipError_t launch_zero_gap_rows(void* buf, const int* seg, int n_seg, int rows, size_t row_bytes, hipStream_t st) {
+    if (n_seg <= 0 || rows <= 0 || row_bytes % 16 != 0 || row_bytes > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(zero_gap_rows_kernel, dim3(n_seg), dim3(256), 0, st, (char*)buf, seg, n_seg, rows, (int)row_bytes);
     return hipGetLastError();
 }
 
@@ -133,12 +155,17 @@ hipError_t launch_packed_stats(const int64_t* tokens, const int* seg, int n_seg,
 __global__ __launch_bounds__(256) void add_positions_kernel(const int64_t* __restrict__ tokens,
                                                              const float* __restrict__ pos_emb,
                                                              float* __restrict__ x, int T, int E, int pad_idx,
-                                                             int npos) {
+                                                             int npos, const int* __restrict__ seg) {
     extern __shared__ int s_pos[];  // [T] position ids + 4 wave totals
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t* row = tokens + (size_t)b * T;
-    int* s_tot = s_pos + T;
+    size_t first = (size_t)b * T;  // first row of the sequence
+    int* s_tot = s_pos + T;        // (T = longest sequence)
+    if (seg != nullptr) {          // token-packed batch: segment b of one row space
+        first = (size_t)seg[2 * b];
+        T = seg[2 * b + 1];
+    }
+    const int64_t* row = tokens + first;
     int carry = 0;
     for (int t0 = 0; t0 < T; t0 += 256) {
         const int t = t0 + tid;
@@ -162,7 +189,7 @@ __global__ __launch_bounds__(256) void add_positions_kernel(const int64_t* __res
         const int t = idx / e4, k = idx - t * e4;
         const int ps = min(s_pos[t], npos - 1);
         const f32x4 pe = reinterpret_cast<const f32x4*>(pos_emb + (size_t)ps * E)[k];
-        f32x4* dst = reinterpret_cast<f32x4*>(x + ((size_t)b * T + t) * E) + k;
+        f32x4* dst = reinterpret_cast<f32x4*>(x + (first + t) * E) + k;
         f32x4 v = *dst;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += pe[e];
@@ -171,10 +198,10 @@ __global__ __launch_bounds__(256) void add_positions_kernel(const int64_t* __res
 }
 
 hipError_t launch_add_positions(const int64_t* tokens, const float* pos_emb, float* x, int B, int T, int E,
-                                int pad_idx, int npos, hipStream_t st) {
+                                int pad_idx, int npos, hipStream_t st, const int* seg) {
     if (E % 4 != 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(add_positions_kernel, dim3(B), dim3(256), (size_t)(T + 4) * sizeof(int), st, tokens, pos_emb,
-                       x, T, E, pad_idx, npos);
+                       x, T, E, pad_idx, npos, seg);
     return hipGetLastError();
 }
 

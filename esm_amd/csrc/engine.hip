@@ -433,8 +433,6 @@ static int check_segments(const char* who, const esmk_model* m, const int32_t* s
     const std::string w(who);
     if (!m || !seg) return fail(w + ": null argument");
     if (m->is_msa) return fail(w + ": not an ESM-2 handle");
-    if (m->cfg.num_positions > 0) return fail(w + ": learned-position models (ESM-1b) take padded batches");
-    if (m->D == 128) return fail(w + ": head_dim 128 takes padded batches");
     if (n_seg <= 0 || rows <= 0) return fail(w + ": n_seg and rows must be positive");
     if (rows % 64 != 0) return fail(w + ": rows must be a multiple of 64");
     if (rows > ESMK_MAX_ROWS) return fail(w + ": rows exceed 2^24");
@@ -607,7 +605,7 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         float* keep = esm1b ? (float*)(ws + w.keep) : nullptr;
         if (pc) {
             ESMK_TRY(launch_packed_stats(tokens_dev, (const int*)(ws + w.tables), pc->n_seg, T, m->cfg.pad_idx,
-                                         m->cfg.mask_idx, scale, key_bias, row_pos, (int*)segs.npad, st));
+                                         m->cfg.mask_idx, scale, key_bias, row_pos, (int*)segs.npad, st, keep));
             // the token-dropout divisor is per row: "sequences" of one token
             ESMK_TRY(launch_embed(tokens_dev, (const float*)(pk + m->embed_f32), scale, x, T, 1, E, m->V,
                                   m->cfg.pad_idx, m->cfg.mask_idx, m->cfg.token_dropout, st));
@@ -619,10 +617,14 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         }
         if (esm1b) {
             // esm1.py:133-139: + learned positions, emb_layer_norm_before, padded positions zeroed
-            if (T > m->cfg.num_positions - m->cfg.pad_idx - 1)
+            if (T_rope > m->cfg.num_positions - m->cfg.pad_idx - 1)
                 return fail("esmk_forward: sequence length above the maximum of the positional embedding");
-            ESMK_TRY(launch_add_positions(tokens_dev, (const float*)(pk + m->pos_emb), x, B, T, E, m->cfg.pad_idx,
-                                          m->cfg.num_positions, st));
+            if (pc)
+                ESMK_TRY(launch_add_positions(tokens_dev, (const float*)(pk + m->pos_emb), x, pc->n_seg, pc->max_len, E,
+                                              m->cfg.pad_idx, m->cfg.num_positions, st, (const int*)(ws + w.tables)));
+            else
+                ESMK_TRY(launch_add_positions(tokens_dev, (const float*)(pk + m->pos_emb), x, B, T, E, m->cfg.pad_idx,
+                                              m->cfg.num_positions, st));
             if (m->cfg.ln_before) {
                 LnExtra ex;
                 ex.row_keep = keep;
@@ -672,7 +674,11 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         {
             // 4 T d flop per (query, head) pair: QK^T and PV; q,k,v read + ctx written
             ProfScope ps(m, st, PC_ATTENTION, pc ? 4.0 * pc->sum_len2 * E : 4.0 * N * (double)T * E, 4 * NE * os);
-            if (pc) ESMK_TRY(launch_attention_packed(q, k, vt, key_bias, h, H, T, w.Tp, segs, pc->n_items, op, st));
+            if (pc)  // gap rows of the context (the rows of h were last read by the two GEMMs above)
+                ESMK_TRY(launch_zero_gap_rows(h, (const int*)(ws + w.tables), pc->n_seg, T, (size_t)EA * os, st));
+            if (pc && m->D == 128)
+                ESMK_TRY(launch_attention128_packed(q, k, vt, key_bias, h, H, T, w.Tp, segs, pc->n_items, op, st));
+            else if (pc) ESMK_TRY(launch_attention_packed(q, k, vt, key_bias, h, H, T, w.Tp, segs, pc->n_items, op, st));
             else if (m->D == 128) ESMK_TRY(launch_attention128(q, k, vt, key_bias, seq_info, h, lse, B, H, T, w.Tp, op, st));
             else ESMK_TRY(launch_attention(q, k, vt, key_bias, seq_info, h, lse, B, H, T, w.Tp, op, st));
         }

@@ -67,8 +67,9 @@ hipError_t launch_seq_stats(const int64_t* tokens, int B, int T, int pad_idx, in
                             int token_dropout, float* scale, float* key_bias, int* seq_info,
                             hipStream_t st, float* keep = nullptr);  // keep[b,t] = 1 - pad (optional)
 // ESM-1b / ESM-1v: x += embed_positions[...] (esm1.py:133, modules.py:240-257); x *= keep (esm1.py:138-139)
+// seg != null: token-packed batch, "sequence" b = segment b = rows [seg[2b], seg[2b] + seg[2b+1]), T = longest
 hipError_t launch_add_positions(const int64_t* tokens, const float* pos_emb, float* x, int B, int T, int E,
-                                int pad_idx, int npos, hipStream_t st);
+                                int pad_idx, int npos, hipStream_t st, const int* seg = nullptr);
 hipError_t launch_scale_rows(float* x, const float* keep, int rows, int E, hipStream_t st);
 // embedding gather + token-dropout rescale + pad zeroing (esm2.py:84-95)
 hipError_t launch_embed(const int64_t* tokens, const float* table, const float* scale, float* x,
@@ -116,7 +117,10 @@ hipError_t launch_contacts(const float* attn, const int64_t* tokens, const float
 //   row_pos[m] = m - segment start (0 in gaps), seg_npad[s] = number of <pad> tokens inside segment s
 hipError_t launch_packed_stats(const int64_t* tokens, const int* seg, int n_seg, int rows, int pad_idx,
                                int mask_idx, float* scale_row, float* key_bias, int* row_pos, int* seg_npad,
-                               hipStream_t st);
+                               hipStream_t st, float* keep = nullptr);  // keep[m] = 1 - pad (0 in gaps), optional
+
+// rows outside every segment of buf[rows][row_bytes] := 0 (the attention kernel does not write them)
+hipError_t launch_zero_gap_rows(void* buf, const int* seg, int n_seg, int rows, size_t row_bytes, hipStream_t st);
 
 // ---- attention.hip ---------------------------------------------------------------------
 // query-block work list of a token-packed batch: work[4i..4i+3] = (first row of the segment, segment length,
@@ -128,6 +132,9 @@ struct AttnSegs {
 hipError_t launch_attention_packed(const void* q, const void* k, const void* vt, const float* key_bias, void* ctx,
                                    int H, int rows, int Tp, AttnSegs segs, int n_items, int operand_dtype,
                                    hipStream_t st);
+hipError_t launch_attention128_packed(const void* q, const void* k, const void* vt, const float* key_bias, void* ctx,
+                                      int H, int rows, int Tp, AttnSegs segs, int n_items, int operand_dtype,
+                                      hipStream_t st);
 hipError_t launch_attention(const void* q, const void* k, const void* vt, const float* key_bias,
                             const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
                             int operand_dtype, hipStream_t st);

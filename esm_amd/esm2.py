@@ -280,10 +280,7 @@ class ESM2(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     # token-packed batches: no compute on padding (include/esmk.h, esmk_forward_packed)
-    @property
-    def supports_varlen(self):
-        """Token-packed batches exist for rotary models with head_dim <= 64 (every ESM-2 but the 15B)."""
-        return int(getattr(self, "_engine_num_positions", 0)) == 0 and self.embed_dim // self.attention_heads <= 64
+    supports_varlen = True  # ESM-2 (all sizes) and ESM-1b / ESM-1v; the MSA Transformer has no such path
 
     def forward_varlen(self, tokens, repr_layers=[], lengths=None, min_saving=0.08, unpack=True):
         """Same results as ``forward(tokens, repr_layers)`` on the non-pad positions of a RIGHT-padded batch

@@ -113,8 +113,8 @@ int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_de
  *   tokens_dev      int64 [rows]
  *   segments_host   int32 [n_seg][2] on the HOST (first row, length incl. <cls>/<eos>)
  *   repr_out_dev[i] fp32 [rows,E]; logits_out_dev fp32 [rows,V] (iff ESMK_OUT_LOGITS); gap rows are undefined
- * Attention maps / contacts are [T,T] per sequence and stay with esmk_forward; so do ESM-1b (learned
- * positions) and head_dim 128 for now: those requests fail with an error. */
+ * ESM-1b / ESM-1v handles work the same way (learned positions restart at each segment, esm/modules.py:240-257).
+ * Attention maps / contacts are [T,T] per sequence and stay with esmk_forward: those flags fail with an error. */
 int esmk_packed_workspace_bytes(const esmk_model* m, int n_seg, int rows, uint32_t out_flags, size_t* bytes);
 int esmk_forward_packed(esmk_model* m, const void* packed_dev, const int64_t* tokens_dev,
                         const int32_t* segments_host, int n_seg, int rows, const int32_t* repr_layers,

@@ -248,6 +248,26 @@ def test_row_guard_fails_loudly():
     assert N.lib.esmk_workspace_bytes(model._engine.handle, 1 << 12, 1 << 12, 0, ctypes.byref(need)) == 0
 
 
+def test_poisoned_workspace():
+    """The engine may not read workspace bytes it has not written: results with the workspace pre-filled with
+    0xFF bytes (NaN in fp16 / fp32) equal the results on a zeroed one, for lengths on and off the 64-key tile."""
+    model, _ = build(2, 320, 20, seed=13)  # head_dim 16: the attention width differs from the embedding width
+    for T in (64, 77, 130):
+        toks = synth_tokens(3, T, seed=T)
+        toks[1, T - 9:] = 1  # one padded sequence
+        toks = toks.cuda()
+        with torch.no_grad():
+            model(toks, repr_layers=[2], return_contacts=True)
+            model._engine.workspace.zero_()
+            a = model(toks, repr_layers=[2], return_contacts=True)
+            model._engine.workspace.fill_(255)
+            b = model(toks, repr_layers=[2], return_contacts=True)
+        keep = toks.ne(1)
+        assert torch.equal(a["representations"][2][keep], b["representations"][2][keep])
+        assert torch.equal(a["logits"][keep], b["logits"][keep])
+        assert torch.equal(a["contacts"], b["contacts"]) and torch.isfinite(b["contacts"]).all()
+
+
 def test_properties_full_length():
     """Size-independent properties at L=1022 with the 650M dimensions (no oracle needed):
     run-to-run determinism, batch-composition invariance (bit exact) and padding invariance."""

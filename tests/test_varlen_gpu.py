@@ -53,6 +53,10 @@ def test_packed_equals_each_sequence_alone(dims):
     model, _ = build(L, E, H, seed=11)
     toks = ragged_batch(LENGTHS, seed=3, masks=[(8, 5), (8, 40), (3, 7)], interior_pad=[(8, 100)])
     with torch.no_grad():
+        model.forward_varlen(toks, repr_layers=[L], min_saving=None)
+        # every byte of the workspace = 0xFF (NaN in fp16 / fp32): nothing may be read before it is written,
+        # and gap rows must not leak into their neighbours
+        model._engine.workspace.fill_(255)
         out = model.forward_varlen(toks, repr_layers=[0, 1, L], min_saving=None)
         for b, n in enumerate(LENGTHS):
             one = model(toks[b:b + 1, :n].cuda(), repr_layers=[0, 1, L])
@@ -101,8 +105,6 @@ def test_packed_layout_and_fallback():
 
 def test_packed_errors_are_loud():
     from esm_amd import _native as N
-    from esm_amd.synth import synth_esm1b_state_dict
-
     model, _ = build(1, 128, 2, seed=2)
     toks = ragged_batch([20, 5], seed=1)
     model.forward_varlen(toks, min_saving=None)
@@ -130,12 +132,42 @@ def test_packed_errors_are_loud():
     assert call([0, 20, 32, 5], N.OUT_LOGITS | N.OUT_CONTACTS) != 0
     assert call([0, 20, 32, 5]) == 0
     torch.cuda.synchronize()
-    # learned-position models stay on padded batches
+
+
+def test_packed_head_dim_128():
+    """esm2_t48_15B geometry (head_dim 128): attention128.hip takes the same segment work list."""
+    L, E, H = 2, 256, 2
+    model, _ = build(L, E, H, seed=4)
+    lengths = [2, 70, 129, 33, 200]
+    toks = ragged_batch(lengths, seed=6, masks=[(1, 9)], interior_pad=[(4, 50)])
+    with torch.no_grad():
+        out = model.forward_varlen(toks, repr_layers=[L], min_saving=None)
+        for b, n in enumerate(lengths):
+            one = model(toks[b:b + 1, :n].cuda(), repr_layers=[L])
+            assert torch.equal(out["representations"][L][b, :n], one["representations"][L][0]), (b, n)
+            assert torch.equal(out["logits"][b, :n], one["logits"][0]), (b, n)
+
+
+@pytest.mark.parametrize("ln_before", [True, False], ids=["esm1b", "esm1v_style"])
+def test_packed_esm1b(ln_before):
+    """Learned positions restart at every segment (esm/modules.py:240-257), padded rows are zeroed after the
+    embedding LayerNorm (esm/model/esm1.py:133-139)."""
     import argparse
 
-    args = argparse.Namespace(arch="roberta_large", layers=1, embed_dim=128, ffn_embed_dim=512, attention_heads=2,
-                              max_positions=1024, token_dropout=True, emb_layer_norm_before=True)
-    m1 = esm.ProteinBertModel(args, esm.Alphabet.from_architecture("roberta_large")).eval()
-    m1.load_state_dict(synth_esm1b_state_dict(1, 128, 2, seed=1, ln_before=True), strict=True)
-    with pytest.raises(RuntimeError, match="padded batches"):
-        m1.cuda().forward_varlen(toks, min_saving=None)
+    from esm_amd.synth import synth_esm1b_state_dict
+
+    L, E, H = 2, 128, 2
+    args = argparse.Namespace(arch="roberta_large", layers=L, embed_dim=E, ffn_embed_dim=4 * E, attention_heads=H,
+                              max_positions=1024, token_dropout=True, emb_layer_norm_before=ln_before)
+    model = esm.ProteinBertModel(args, esm.Alphabet.from_architecture("roberta_large")).eval()
+    model.load_state_dict(synth_esm1b_state_dict(L, E, H, seed=1, ln_before=ln_before), strict=True)
+    model = model.cuda()
+    lengths = [40, 2, 150, 65, 300]
+    toks = ragged_batch(lengths, seed=8, masks=[(0, 3), (4, 77)], interior_pad=[(2, 30)])
+    with torch.no_grad():
+        out = model.forward_varlen(toks, repr_layers=[0, L], min_saving=None)
+        for b, n in enumerate(lengths):
+            one = model(toks[b:b + 1, :n].cuda(), repr_layers=[0, L])
+            for layer in (0, L):
+                assert torch.equal(out["representations"][layer][b, :n], one["representations"][layer][0]), (b, n, layer)
+            assert torch.equal(out["logits"][b, :n], one["logits"][0]), (b, n)
