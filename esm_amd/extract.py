@@ -189,18 +189,21 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
     def finish(ids, labels, strs, reps, contacts, means_b):
         """Per-sequence results of one batch from HOST tensors (reference scripts/extract.py:104-131)."""
         rows_idx, rows_mean = [], {l: [] for l in layers}
+        # slices are cloned only when they are kept (saved): torch.save of a view would write the whole batch,
+        # and a 5 MB clone per sequence costs more host time (fresh pages) than the device->host copy itself
+        own = (lambda t: t.clone()) if output_dir is not None else (lambda t: t)
         for row, (seq_id, label) in enumerate(zip(ids, labels)):
             n = min(truncation_seq_length, len(strs[row]))
             result = {"label": label}
             if "per_tok" in include:
-                result["representations"] = {l: t[row, 1:n + 1].clone() for l, t in reps.items()}
+                result["representations"] = {l: own(t[row, 1:n + 1]) for l, t in reps.items()}
             means = {l: means_b[l][row] for l in reps}
             if "mean" in include:
                 result["mean_representations"] = {l: m.clone() for l, m in means.items()}
             if "bos" in include:
-                result["bos_representations"] = {l: t[row, 0].clone() for l, t in reps.items()}
+                result["bos_representations"] = {l: own(t[row, 0]) for l, t in reps.items()}
             if contacts is not None:
-                result["contacts"] = contacts[row, :n, :n].clone()
+                result["contacts"] = own(contacts[row, :n, :n])
             if output_dir is not None:
                 path = output_dir / f"{label}.pt"
                 path.parent.mkdir(parents=True, exist_ok=True)
@@ -277,6 +280,20 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
     return gathered
 
 
+def make_embed_fn(model, varlen: bool = True):
+    """The ``embed_fn`` of :func:`extract` for an engine model: token-packed batches (no compute on padding)
+    where the model has them and no contact maps are asked for (those are per-sequence [T,T]: padded path)."""
+    varlen = varlen and getattr(model, "supports_varlen", False)
+
+    def embed_fn(toks, layers, return_contacts, lengths=None):
+        if varlen and not return_contacts:
+            return model.forward_varlen(toks, repr_layers=layers, lengths=lengths)
+        return model(toks, repr_layers=layers, return_contacts=return_contacts)
+
+    embed_fn.wants_lengths = True
+    return embed_fn
+
+
 def create_parser():
     p = argparse.ArgumentParser(description="Sharded per-token / mean representation extraction on MI355X GPUs")
     p.add_argument("model_location", type=str)
@@ -316,14 +333,7 @@ def main(argv=None):
     if rank == 0:
         print(f"Read {args.fasta_file} with {len(dataset)} sequences; {world} rank(s)")
 
-    varlen = (not args.no_varlen) and getattr(model, "supports_varlen", False)
-
-    def embed_fn(toks, layers, return_contacts, lengths=None):
-        if varlen and not return_contacts:  # no compute on padding (contact maps are per-sequence [T,T]: padded path)
-            return model.forward_varlen(toks, repr_layers=layers, lengths=lengths)
-        return model(toks, repr_layers=layers, return_contacts=return_contacts)
-
-    embed_fn.wants_lengths = True
+    embed_fn = make_embed_fn(model, varlen=not args.no_varlen)
 
     means = extract(dataset, alphabet, embed_fn, model.num_layers, model.embed_dim, args.repr_layers, args.include,
                     output_dir=args.output_dir, toks_per_batch=args.toks_per_batch,
