@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libesmk.so")
 
 F32, F16, BF16 = 0, 1, 2
-OUT_LOGITS, OUT_ATTN, OUT_CONTACTS, OUT_COL_ATTN = 1, 2, 4, 8
+OUT_LOGITS, OUT_ATTN, OUT_CONTACTS, OUT_COL_ATTN, OUT_REPR_LOWP, OUT_ATTN_LOWP = 1, 2, 4, 8, 16, 32
 EPI_STORE_T, EPI_STORE_F32, EPI_GELU_T, EPI_GELU_F32, EPI_RESID_F32 = 0, 1, 2, 3, 4
 
 

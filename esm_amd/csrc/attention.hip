@@ -614,12 +614,13 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
 // ---------------------------------------------------------------------------------------------
 // attention probabilities for need_head_weights / contacts
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+// O = float (the reference's fp32 maps) or T (ESMK_OUT_ATTN_LOWP: `.half()` models, esmfold.py:61-67,131-135)
+template <typename T, typename O = float>
 __global__ __launch_bounds__(256) void attn_probs_kernel(const T* __restrict__ q,
                                                           const T* __restrict__ k,
                                                           const float* __restrict__ lse,
                                                           const float* __restrict__ key_bias,
-                                                          float* __restrict__ probs, int H, int Tlen,
+                                                          O* __restrict__ probs, int H, int Tlen,
                                                           int layer, int Ltot, int msa_C,
                                                           const int* __restrict__ any_pad) {
     // msa_C > 0: MSA column attention (axial_attention.py:207-218).  The "sequence" b is (batch, column),
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const T* __restrict__ q
         row_lse[r] = lse[(size_t)bh * Tlen + qc];
         row_keep[r] = (!fill && key_bias != nullptr && key_bias[(size_t)b * Tlen + qc] != 0.f) ? 0.f : 1.f;
     }
-    float* out = probs + (((size_t)b * Ltot + layer) * H + head) * (size_t)Tlen * Tlen;
+    O* out = probs + (((size_t)b * Ltot + layer) * H + head) * (size_t)Tlen * Tlen;
     if (fill) {
         const int bm = b / msa_C, c = b - bm * msa_C;
         out = probs + ((((size_t)bm * Ltot + layer) * H + head) * msa_C + c) * (size_t)Tlen * Tlen;
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const T* __restrict__ q
                 if (qr < Tlen) {
                     const float sc = (fill && kb != 0.f) ? -10000.f : s[r] + kb;  // masked_fill vs additive -inf
                     const float p = __expf(sc - row_lse[r]) * row_keep[r];
-                    out[(size_t)qr * Tlen + key] = p;
+                    out[(size_t)qr * Tlen + key] = (O)p;
                 }
             }
         }
@@ -688,8 +689,20 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const T* __restrict__ q
 
 static hipError_t launch_probs_impl(const void* q, const void* k, const float* lse, const float* key_bias,
                                     float* probs, int B, int H, int T, int layer, int num_layers_total,
-                                    int operand_dtype, int msa_C, const int* any_pad, hipStream_t st) {
+                                    int operand_dtype, int msa_C, const int* any_pad, hipStream_t st,
+                                    bool lowp = false) {
     dim3 grid((unsigned)(((T + 127) / 128) * B * H));
+    if (lowp) {  // maps in the operand dtype
+        if (operand_dtype == ESMK_DT_BF16)
+            hipLaunchKernelGGL((attn_probs_kernel<__bf16, __bf16>), grid, dim3(256), 0, st, (const __bf16*)q,
+                               (const __bf16*)k, lse, key_bias, (__bf16*)probs, H, T, layer, num_layers_total, msa_C,
+                               any_pad);
+        else
+            hipLaunchKernelGGL((attn_probs_kernel<_Float16, _Float16>), grid, dim3(256), 0, st, (const _Float16*)q,
+                               (const _Float16*)k, lse, key_bias, (_Float16*)probs, H, T, layer, num_layers_total,
+                               msa_C, any_pad);
+        return hipGetLastError();
+    }
     if (operand_dtype == ESMK_DT_BF16)
         hipLaunchKernelGGL((attn_probs_kernel<__bf16>), grid, dim3(256), 0, st, (const __bf16*)q,
                            (const __bf16*)k, lse, key_bias, probs, H, T, layer, num_layers_total, msa_C, any_pad);
@@ -703,9 +716,9 @@ static hipError_t launch_probs_impl(const void* q, const void* k, const float* l
 hipError_t launch_attention_probs(const void* q, const void* k, const float* lse,
                                   const float* key_bias, float* probs, int B, int H, int T,
                                   int layer, int num_layers_total, int operand_dtype,
-                                  hipStream_t st) {
+                                  hipStream_t st, bool lowp) {
     return launch_probs_impl(q, k, lse, key_bias, probs, B, H, T, layer, num_layers_total, operand_dtype, 0,
-                             nullptr, st);
+                             nullptr, st, lowp);
 }
 
 hipError_t launch_attention_probs_msa(const void* q, const void* k, const float* lse, const float* key_fill,

@@ -279,11 +279,11 @@ hipError_t launch_attention128(const void* q, const void* k, const void* vt, con
 // ---------------------------------------------------------------------------------------------
 // attention probabilities for need_head_weights / contacts (multihead_attention.py:396-403)
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, typename O = float>
 __global__ __launch_bounds__(256) void attn_probs128_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                              const float* __restrict__ lse,
                                                              const float* __restrict__ key_bias,
-                                                             float* __restrict__ probs, int H, int Tlen, int layer,
+                                                             O* __restrict__ probs, int H, int Tlen, int layer,
                                                              int Ltot) {
     using V8 = typename Op<T>::v8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_probs128_kernel(const T* __restrict_
         row_lse[r] = lse[(size_t)bh * Tlen + qc];
         row_keep[r] = (key_bias != nullptr && key_bias[(size_t)b * Tlen + qc] != 0.f) ? 0.f : 1.f;
     }
-    float* out = probs + (((size_t)b * Ltot + layer) * H + head) * (size_t)Tlen * Tlen;
+    O* out = probs + (((size_t)b * Ltot + layer) * H + head) * (size_t)Tlen * Tlen;
     for (int k0 = 0; k0 < Tlen; k0 += 32) {
         const int key = k0 + lm;
         const int kc = min(key, Tlen - 1);
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void attn_probs128_kernel(const T* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qr = q0 + mfma32_row(r, h);
-                if (qr < Tlen) out[(size_t)qr * Tlen + key] = __expf(s[r] + kbv - row_lse[r]) * row_keep[r];
+                if (qr < Tlen) out[(size_t)qr * Tlen + key] = (O)(__expf(s[r] + kbv - row_lse[r]) * row_keep[r]);
             }
         }
     }
@@ -333,8 +333,17 @@ __global__ __launch_bounds__(256) void attn_probs128_kernel(const T* __restrict_
 
 hipError_t launch_attention_probs128(const void* q, const void* k, const float* lse, const float* key_bias,
                                      float* probs, int B, int H, int T, int layer, int num_layers_total,
-                                     int operand_dtype, hipStream_t st) {
+                                     int operand_dtype, hipStream_t st, bool lowp) {
     dim3 grid((unsigned)(((T + 127) / 128) * B * H));
+    if (lowp) {  // maps in the operand dtype (ESMK_OUT_ATTN_LOWP)
+        if (operand_dtype == ESMK_DT_BF16)
+            hipLaunchKernelGGL((attn_probs128_kernel<__bf16, __bf16>), grid, dim3(256), 0, st, (const __bf16*)q,
+                               (const __bf16*)k, lse, key_bias, (__bf16*)probs, H, T, layer, num_layers_total);
+        else
+            hipLaunchKernelGGL((attn_probs128_kernel<_Float16, _Float16>), grid, dim3(256), 0, st, (const _Float16*)q,
+                               (const _Float16*)k, lse, key_bias, (_Float16*)probs, H, T, layer, num_layers_total);
+        return hipGetLastError();
+    }
     if (operand_dtype == ESMK_DT_BF16)
         hipLaunchKernelGGL((attn_probs128_kernel<__bf16>), grid, dim3(256), 0, st, (const __bf16*)q, (const __bf16*)k,
                            lse, key_bias, probs, H, T, layer, num_layers_total);

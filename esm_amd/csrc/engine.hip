@@ -73,6 +73,7 @@ void plan_packed(esmk_model* m) {
 
 struct Workspace {
     size_t scale, key_bias, seq_info, keep, x, h, big, lse, ct_scratch, total;
+    size_t ct_acc, ct_row, ct_col, ct_rowp, ct_colp, ct_wt;  // contacts without attention maps (contacts.hip)
     size_t q, k, vt;  // inside big
     int Tp;
     size_t row_pos, tables;  // token-packed batches only
@@ -115,8 +116,17 @@ Workspace plan_workspace(const esmk_model* m, int B, int T, uint32_t flags, int 
     const bool attn = flags & (ESMK_OUT_ATTN | ESMK_OUT_CONTACTS);
     w.lse = c.take(attn ? (size_t)B * m->H * T * 4 : 0);
     const int S = T - (m->cfg.prepend_bos ? 1 : 0) - (m->cfg.append_eos ? 1 : 0);
-    w.ct_scratch =
-        c.take((flags & ESMK_OUT_CONTACTS) ? (size_t)B * m->L * m->H * (size_t)(S > 0 ? S + 1 : 1) * 4 : 0);
+    // ESMK_OUT_CONTACTS without ESMK_OUT_ATTN: no [B,L,H,T,T] tensor anywhere (contacts.hip)
+    const bool fused_ct = (flags & ESMK_OUT_CONTACTS) && !(flags & ESMK_OUT_ATTN);
+    w.ct_scratch = c.take(((flags & ESMK_OUT_CONTACTS) && !fused_ct)
+                              ? (size_t)B * m->L * m->H * (size_t)(S > 0 ? S + 1 : 1) * 4 : 0);
+    const size_t C = (size_t)m->L * m->H;
+    w.ct_acc = c.take(fused_ct ? (size_t)contacts_head_groups(B, T, m->H, m->D == 128 ? 128 : 64) * B * T * T * 4 : 0);
+    w.ct_row = c.take(fused_ct ? (size_t)B * C * T * 4 : 0);
+    w.ct_col = c.take(fused_ct ? (size_t)B * C * T * 4 : 0);
+    w.ct_rowp = c.take(fused_ct ? (size_t)B * ((T + 127) / 128) * m->H * T * 4 : 0);
+    w.ct_colp = c.take(fused_ct ? (size_t)B * ((T + 31) / 32) * m->H * T * 4 : 0);
+    w.ct_wt = c.take(fused_ct ? (size_t)B * C * 4 : 0);
     if (packed_segs > 0) {
         w.row_pos = c.take(N * 4);
         // [seg 2 n_seg][npad n_seg][work 4 n_items]
@@ -463,7 +473,8 @@ int esmk_packed_workspace_bytes(const esmk_model* m, int n_seg, int rows, uint32
     if (!m || !bytes) return fail("esmk_packed_workspace_bytes: null argument");
     if (n_seg <= 0 || rows <= 0 || rows % 64 != 0 || rows > ESMK_MAX_ROWS)
         return fail("esmk_packed_workspace_bytes: need n_seg > 0 and 0 < rows <= 2^24, rows % 64 == 0");
-    if (out_flags & ~(uint32_t)ESMK_OUT_LOGITS) return fail("esmk_packed_workspace_bytes: only ESMK_OUT_LOGITS is available");
+    if (out_flags & ~(uint32_t)(ESMK_OUT_LOGITS | ESMK_OUT_REPR_LOWP))
+        return fail("esmk_packed_workspace_bytes: only ESMK_OUT_LOGITS / ESMK_OUT_REPR_LOWP are available");
     *bytes = plan_workspace(m, 1, rows, out_flags, n_seg).total;
     return 0;
 }
@@ -474,7 +485,7 @@ int esmk_forward_packed(esmk_model* m, const void* packed_dev, const int64_t* to
                         void* workspace_dev, size_t workspace_bytes, void* stream) {
     PackedCtx pc;
     if (check_segments("esmk_forward_packed", m, segments_host, n_seg, rows, &pc)) return 1;
-    if (out_flags & ~(uint32_t)ESMK_OUT_LOGITS)
+    if (out_flags & ~(uint32_t)(ESMK_OUT_LOGITS | ESMK_OUT_REPR_LOWP))
         return fail("esmk_forward_packed: attention maps and contacts take padded batches (esmk_forward)");
     return forward_impl(m, packed_dev, tokens_dev, 1, rows, repr_layers, n_repr, repr_out_dev, out_flags,
                         logits_out_dev, nullptr, nullptr, workspace_dev, workspace_bytes, stream, &pc);
@@ -491,7 +502,13 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
     if (n_repr > 0 && (!repr_layers || !repr_out_dev)) return fail("esmk_forward: null repr arrays");
     const bool want_logits = out_flags & ESMK_OUT_LOGITS;
     const bool want_contacts = out_flags & ESMK_OUT_CONTACTS;
-    const bool want_attn = (out_flags & ESMK_OUT_ATTN) || want_contacts;
+    // contacts alone (predict_contacts, esm2.py:146-147): accumulated layer by layer, no attention tensor
+    const bool fused_ct = want_contacts && !(out_flags & ESMK_OUT_ATTN);
+    const bool want_attn = (out_flags & ESMK_OUT_ATTN) != 0;
+    const int S_ct = T - (m->cfg.prepend_bos ? 1 : 0) - (m->cfg.append_eos ? 1 : 0);
+    const bool repr_lowp = out_flags & ESMK_OUT_REPR_LOWP, attn_lowp = out_flags & ESMK_OUT_ATTN_LOWP;
+    if (attn_lowp && want_attn && want_contacts)
+        return fail("esmk_forward: ESMK_OUT_ATTN_LOWP cannot be combined with contacts computed from the attention tensor");
     if (want_logits && !logits_out_dev) return fail("esmk_forward: logits buffer missing");
     if (want_attn && !attn_out_dev) return fail("esmk_forward: attention buffer missing");
     if (want_contacts && !contacts_out_dev) return fail("esmk_forward: contacts buffer missing");
@@ -517,7 +534,7 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
     void* vt = ws + w.vt;
     void* ffn = ws + w.big;
     float* g32 = (float*)(ws + w.big);
-    float* lse = want_attn ? (float*)(ws + w.lse) : nullptr;
+    float* lse = (want_attn || fused_ct) ? (float*)(ws + w.lse) : nullptr;
 
     const int T_rope = pc ? pc->max_len : T;  // longest run of positions
     if (m->cfg.no_rope) {
@@ -570,8 +587,9 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
     auto repr_copy = [&](int layer, const float* src) -> int {
         for (int i = 0; i < n_repr; ++i)
             if (repr_layers[i] == layer) {
-                ProfScope ps(m, st, PC_COPY, 0, 8 * NE);
-                ESMK_TRY(launch_copy_f32(src, (float*)repr_out_dev[i], (size_t)N * E, st));
+                ProfScope ps(m, st, PC_COPY, 0, (repr_lowp ? 4 + os : 8) * NE);
+                if (repr_lowp) ESMK_TRY(launch_convert(src, ESMK_DT_F32, repr_out_dev[i], op, (size_t)N * E, st));
+                else ESMK_TRY(launch_copy_f32(src, (float*)repr_out_dev[i], (size_t)N * E, st));
             }
         return 0;
     };
@@ -682,12 +700,25 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
             else if (m->D == 128) ESMK_TRY(launch_attention128(q, k, vt, key_bias, seq_info, h, lse, B, H, T, w.Tp, op, st));
             else ESMK_TRY(launch_attention(q, k, vt, key_bias, seq_info, h, lse, B, H, T, w.Tp, op, st));
         }
+        if (fused_ct && S_ct > 0) {
+            // q, k and lse of this layer are still in the workspace: add the layer's channels to the
+            // [B,T,T] accumulator and the per-channel masked row / column sums
+            ProfScope ps(m, st, PC_ATTN_PROBS, 2.0 * N * (double)T * E, 2 * NE * os + 8.0 * N * T);
+            ESMK_TRY(launch_contacts_fused_layer(q, k, lse, key_bias, tokens_dev, (const float*)(pk + m->ct_w),
+                                                 (float*)(ws + w.ct_acc), (float*)(ws + w.ct_row),
+                                                 (float*)(ws + w.ct_col), (float*)(ws + w.ct_rowp),
+                                                 (float*)(ws + w.ct_colp), B, H, T, L * H, l,
+                                                 m->D == 128 ? 128 : 64, m->cfg.pad_idx, m->cfg.eos_idx,
+                                                 m->cfg.prepend_bos, m->cfg.append_eos, op, st));
+        }
         if (want_attn) {
             ProfScope ps(m, st, PC_ATTN_PROBS, 2.0 * N * (double)T * E, 2 * NE * os + 4.0 * N * T * H);
             if (m->D == 128)
-                ESMK_TRY(launch_attention_probs128(q, k, lse, key_bias, (float*)attn_out_dev, B, H, T, l, L, op, st));
+                ESMK_TRY(launch_attention_probs128(q, k, lse, key_bias, (float*)attn_out_dev, B, H, T, l, L, op, st,
+                                                   attn_lowp));
             else
-                ESMK_TRY(launch_attention_probs(q, k, lse, key_bias, (float*)attn_out_dev, B, H, T, l, L, op, st));
+                ESMK_TRY(launch_attention_probs(q, k, lse, key_bias, (float*)attn_out_dev, B, H, T, l, L, op, st,
+                                                attn_lowp));
         }
         g = GemmArgs();
         g.A = h;
@@ -727,7 +758,20 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
             rep_last = (float*)repr_out_dev[i];
             break;
         }
-    if (want_logits || wants_repr(L)) {
+    if (repr_lowp && rep_last != nullptr) {
+        // representation L in the operand dtype: the normalised rows h ARE that tensor when their row stride is E
+        void* rep_lp = rep_last;
+        if (Kp == E) {
+            if (lnorm(x, m->fin_g, m->fin_b, want_logits ? h : rep_lp, nullptr)) return 1;
+            if (want_logits) ESMK_TRY(hipMemcpyAsync(rep_lp, h, (size_t)N * E * os, hipMemcpyDeviceToDevice, st));
+        } else {  // padded row stride (E = 480): through the fp32 scratch
+            if (lnorm(x, m->fin_g, m->fin_b, want_logits ? h : nullptr, g32)) return 1;
+            ESMK_TRY(launch_convert(g32, ESMK_DT_F32, rep_lp, op, (size_t)N * E, st));
+        }
+        for (int i = 0; i < n_repr; ++i)  // duplicates of layer L, if any
+            if (repr_layers[i] == L && repr_out_dev[i] != rep_lp)
+                ESMK_TRY(hipMemcpyAsync(repr_out_dev[i], rep_lp, (size_t)N * E * os, hipMemcpyDeviceToDevice, st));
+    } else if (want_logits || wants_repr(L)) {
         if (lnorm(x, m->fin_g, m->fin_b, want_logits ? h : nullptr, rep_last)) return 1;
         for (int i = 0; i < n_repr; ++i)  // duplicates of layer L, if any
             if (repr_layers[i] == L && repr_out_dev[i] != rep_last)
@@ -754,7 +798,15 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         g.K = Kp;
         if (gemm(PC_LM_LOGITS, g, EPI_STORE_F32, 4)) return 1;
     }
-    if (want_contacts && T - (m->cfg.prepend_bos ? 1 : 0) - (m->cfg.append_eos ? 1 : 0) > 0) {  // esm2.py:140-142
+    if (fused_ct && S_ct > 0) {
+        ProfScope ps(m, st, PC_CONTACTS, 0, 4.0 * B * ((double)T * T * 2 + 3.0 * L * H * T));
+        ESMK_TRY(launch_contacts_fused_final((const float*)(ws + w.ct_acc), (float*)(ws + w.ct_row),
+                                             (const float*)(ws + w.ct_col), (float*)(ws + w.ct_wt), tokens_dev,
+                                             (const float*)(pk + m->ct_w), (const float*)(pk + m->ct_b),
+                                             (float*)contacts_out_dev, B, H, L * H, T, m->D == 128 ? 128 : 64,
+                                             m->cfg.pad_idx, m->cfg.eos_idx, m->cfg.prepend_bos, m->cfg.append_eos,
+                                             st));
+    } else if (want_contacts && S_ct > 0) {  // esm2.py:140-142
         // (an empty sequence has an empty [B,0,0] contact map: nothing to compute)
         ProfScope ps(m, st, PC_CONTACTS, 0, 2.0 * 4 * B * (double)L * H * T * T);
         ESMK_TRY(launch_contacts((const float*)attn_out_dev, tokens_dev, (const float*)(pk + m->ct_w),

@@ -111,6 +111,22 @@ hipError_t launch_contacts(const float* attn, const int64_t* tokens, const float
                            const float* b, float* scratch, float* out, int B, int C, int T,
                            int eos_idx, int prepend_bos, int append_eos, hipStream_t st);
 
+// contacts.hip — contact maps without the [B,L,H,T,T] attention tensor (predict_contacts, esm2.py:146-147).
+// Per layer, after the attention kernel (q, k, lse still in the workspace): A[G][B,T,T] += sum_h w[layer,h] P_h
+// (G = contacts_head_groups(B,T,H) accumulators, one per head group), rowsum / colsum [B,C,T] (C = L*H) masked sums
+// of every channel; rowp [B, ceil(T/128), H, T] and colp [B, ceil(T/32), H, T] are per-layer scratch.
+int contacts_head_groups(int B, int T, int H, int head_dim);
+hipError_t launch_contacts_fused_layer(const void* q, const void* k, const float* lse, const float* key_bias,
+                                       const int64_t* tokens, const float* wreg, float* acc, float* rowsum,
+                                       float* colsum, float* rowp, float* colp, int B, int H, int T, int C, int layer,
+                                       int head_dim, int pad_idx, int eos_idx, int prepend_bos, int append_eos,
+                                       int operand_dtype, hipStream_t st);
+// after the last layer: rowsum becomes r_c (in place), wt [B,C] = w_c / t_c, out [B,S,S] = sigmoid(logits)
+hipError_t launch_contacts_fused_final(const float* acc, float* rowsum, const float* colsum, float* wt,
+                                       const int64_t* tokens, const float* wreg, const float* bias, float* out,
+                                       int B, int H, int C, int T, int head_dim, int pad_idx, int eos_idx,
+                                       int prepend_bos, int append_eos, hipStream_t st);
+
 // token-packed batch (esmk_forward_packed): per-row bookkeeping of the packed row space.  Segment s occupies
 // rows [seg[2s], seg[2s] + seg[2s+1]); rows outside every segment are gaps.
 //   scale_row[m] = 1 - n_mask/len of m's segment (esm2.py:91-92; 1 in gaps), key_bias[m] = 0 / -inf (pad, gap),
@@ -142,9 +158,10 @@ hipError_t launch_attention(const void* q, const void* k, const void* vt, const 
 hipError_t launch_attention128(const void* q, const void* k, const void* vt, const float* key_bias,
                                const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
                                int operand_dtype, hipStream_t st);
+// lowp: the maps are written in the operand dtype (probs points to fp16 / bf16 storage)
 hipError_t launch_attention_probs128(const void* q, const void* k, const float* lse, const float* key_bias,
                                      float* probs, int B, int H, int T, int layer, int num_layers_total,
-                                     int operand_dtype, hipStream_t st);
+                                     int operand_dtype, hipStream_t st, bool lowp = false);
 // same kernel, MSA column attention: key_fill[b,t] != 0 REPLACES the score by -10000 (masked_fill,
 // axial_attention.py:211-215) and is only applied when any_pad[0] != 0
 hipError_t launch_attention_fill(const void* q, const void* k, const void* vt, const float* key_fill,
@@ -157,6 +174,6 @@ hipError_t launch_attention_probs_msa(const void* q, const void* k, const float*
 hipError_t launch_attention_probs(const void* q, const void* k, const float* lse,
                                   const float* key_bias, float* probs, int B, int H, int T,
                                   int layer, int num_layers_total, int operand_dtype,
-                                  hipStream_t st);
+                                  hipStream_t st, bool lowp = false);
 
 }  // namespace esmk

@@ -76,11 +76,11 @@ class ProteinBertModel(ESM2):
     def num_layers(self, v):  # ESM2.__init__ is bypassed; kept so generic code may assign
         self.args.layers = v
 
-    def forward(self, tokens, repr_layers=[], need_head_weights=False, return_contacts=False):
+    def forward(self, tokens, repr_layers=[], need_head_weights=False, return_contacts=False, **kw):
         if tokens.ndim == 2 and tokens.size(1) > self.embed_positions.max_positions:
             raise ValueError(f"Sequence length {tokens.size(1)} above maximum  sequence length of "
                              f"{self.embed_positions.max_positions}")
-        return super().forward(tokens, repr_layers, need_head_weights, return_contacts)
+        return super().forward(tokens, repr_layers, need_head_weights, return_contacts, **kw)
 
 
 def build_from_checkpoint(model_data):

@@ -80,6 +80,16 @@ class ContactPredictionHead(_Container):
         self.regression = nn.Linear(in_features, 1, bias)
 
 
+def _native_lowp(param_dtype, operand_dtype):
+    """``.half()`` / ``.bfloat16()`` models return fp16 / bf16 tensors (the reference runs the whole module in that
+    dtype; ESMFold's front end does so, esmfold/v1/esmfold.py:61-67).  When the model dtype is the engine's operand
+    dtype the engine writes representations / attention maps in it directly (ESMK_OUT_REPR_LOWP / _ATTN_LOWP);
+    ``ESM_AMD_NATIVE_LOWP=0`` falls back to fp32 outputs + a cast (same bits, one more pass; used by the tests)."""
+    if os.environ.get("ESM_AMD_NATIVE_LOWP", "1") == "0":
+        return False
+    return param_dtype in (torch.float16, torch.bfloat16) and param_dtype == operand_dtype
+
+
 def _operand_dtype_for(param_dtype):
     env = os.environ.get("ESM_AMD_OPERAND", "").lower()
     if env in ("bf16", "bfloat16"):
@@ -228,8 +238,13 @@ class ESM2(nn.Module):
             object.__setattr__(self, "_engine", eng)
         return eng
 
-    def forward(self, tokens, repr_layers=[], need_head_weights=False, return_contacts=False):
-        if return_contacts:
+    def forward(self, tokens, repr_layers=[], need_head_weights=False, return_contacts=False, contacts_only=False):
+        """Reference esm/model/esm2.py:77-144.  ``contacts_only=True`` (engine extension, used by ``predict_contacts``
+        and the extraction driver) returns ``{"contacts", "representations"}`` only: no logits and no [B,L,H,T,T]
+        "attentions" tensor is built — the contact map is accumulated layer by layer (csrc/contacts.hip)."""
+        if contacts_only:
+            return_contacts, need_head_weights = True, False
+        if return_contacts and not contacts_only:
             need_head_weights = True
         assert tokens.ndim == 2
         if not tokens.is_cuda:
@@ -250,14 +265,22 @@ class ESM2(nn.Module):
             eng = self._get_engine(dev)
             eng.sync_weights(self)
             tok = tokens.to(torch.int64).contiguous()
-            flags = N.OUT_LOGITS
+            # predict_contacts: no logits, no attention tensor (contacts.hip accumulates the map layer by layer)
+            flags = 0 if contacts_only else N.OUT_LOGITS
             f32 = dict(dtype=torch.float32, device=dev)
-            logits = torch.empty((B, T, V), **f32)
-            reps = [torch.empty((B, T, E), **f32) for _ in repr_set]
+            lowp = _native_lowp(w.dtype, eng.operand_dtype)
+            logits = None if contacts_only else torch.empty((B, T, V), **f32)
+            if lowp and repr_set:
+                flags |= N.OUT_REPR_LOWP
+            reps = [torch.empty((B, T, E), dtype=w.dtype if lowp else torch.float32, device=dev) for _ in repr_set]
             attn = contacts = None
             if need_head_weights:
                 flags |= N.OUT_ATTN
-                attn = torch.empty((B, L, H, T, T), **f32)
+                if lowp and not return_contacts:  # the contact kernels read fp32 maps
+                    flags |= N.OUT_ATTN_LOWP
+                    attn = torch.empty((B, L, H, T, T), dtype=w.dtype, device=dev)
+                else:
+                    attn = torch.empty((B, L, H, T, T), **f32)
             if return_contacts:
                 S = max(T - int(self.prepend_bos) - int(self.append_eos), 0)
                 contacts = torch.empty((B, S, S), **f32)
@@ -270,7 +293,9 @@ class ESM2(nn.Module):
                 eng.handle, N.ptr(eng.packed), N.ptr(tok), B, T, layers_arr, len(repr_set), outs_arr,
                 flags, N.ptr(logits), N.ptr(attn), N.ptr(contacts), N.ptr(ws), ws.numel(), N.cur_stream()))
         out_dt = w.dtype
-        cast = (lambda t: t) if out_dt == torch.float32 else (lambda t: t.to(out_dt))
+        cast = lambda t: t if t.dtype == out_dt else t.to(out_dt)
+        if contacts_only:
+            return {"contacts": cast(contacts), "representations": {l: cast(r) for l, r in zip(repr_set, reps)}}
         result = {"logits": cast(logits), "representations": {l: cast(r) for l, r in zip(repr_set, reps)}}
         if need_head_weights:
             result["attentions"] = cast(attn)
@@ -281,6 +306,7 @@ class ESM2(nn.Module):
     # ------------------------------------------------------------------------------------------
     # token-packed batches: no compute on padding (include/esmk.h, esmk_forward_packed)
     supports_varlen = True  # ESM-2 (all sizes) and ESM-1b / ESM-1v; the MSA Transformer has no such path
+    supports_contacts_only = True  # forward(contacts_only=True): contact maps without the attention tensor
 
     def forward_varlen(self, tokens, repr_layers=[], lengths=None, min_saving=0.08, unpack=True):
         """Same results as ``forward(tokens, repr_layers)`` on the non-pad positions of a RIGHT-padded batch
@@ -315,19 +341,21 @@ class ESM2(nn.Module):
             idx, keep = plan.index(dev)
             flat = plan.pack(tokens, self.padding_idx, idx)
             f32 = dict(dtype=torch.float32, device=dev)
+            lowp = _native_lowp(w.dtype, eng.operand_dtype) and bool(repr_set)
+            pflags = N.OUT_LOGITS | (N.OUT_REPR_LOWP if lowp else 0)
             logits = torch.empty((plan.rows, V), **f32)
-            reps = [torch.empty((plan.rows, E), **f32) for _ in repr_set]
-            ws = eng.workspace_for_packed(B, plan.rows, N.OUT_LOGITS)
+            reps = [torch.empty((plan.rows, E), dtype=w.dtype if lowp else torch.float32, device=dev) for _ in repr_set]
+            ws = eng.workspace_for_packed(B, plan.rows, pflags)
             seg = plan.segments  # int32 [B,2], CPU, contiguous
             layers_arr = (ctypes.c_int32 * max(1, len(repr_set)))(*repr_set)
             outs_arr = (ctypes.c_void_p * max(1, len(repr_set)))(*[r.data_ptr() for r in reps])
             N.check(N.lib.esmk_forward_packed(
                 eng.handle, N.ptr(eng.packed), N.ptr(flat),
                 ctypes.cast(seg.data_ptr(), ctypes.POINTER(ctypes.c_int32)), B, plan.rows,
-                layers_arr, len(repr_set), outs_arr, N.OUT_LOGITS, N.ptr(logits), N.ptr(ws), ws.numel(),
+                layers_arr, len(repr_set), outs_arr, pflags, N.ptr(logits), N.ptr(ws), ws.numel(),
                 N.cur_stream()))
         out_dt = w.dtype
-        cast = (lambda t: t) if out_dt == torch.float32 else (lambda t: t.to(out_dt))
+        cast = lambda t: t if t.dtype == out_dt else t.to(out_dt)
         if not unpack:
             return {"logits": cast(logits), "representations": {l: cast(r) for l, r in zip(repr_set, reps)},
                     "segments": seg}
@@ -364,4 +392,7 @@ class ESM2(nn.Module):
         return state
 
     def predict_contacts(self, tokens):
-        return self(tokens, return_contacts=True)["contacts"]
+        """Reference esm2.py:146-147 returns ``self(tokens, return_contacts=True)["contacts"]``, which first builds
+        the [B,L,H,T,T] attention tensor (2.8 GB per 1024-token sequence at 650M).  Only the map leaves this call, so
+        the engine accumulates it layer by layer instead (csrc/contacts.hip) — same formula, no attention tensor."""
+        return self(tokens, return_contacts=True, contacts_only=True)["contacts"]

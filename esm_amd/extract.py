@@ -288,6 +288,9 @@ def make_embed_fn(model, varlen: bool = True):
     def embed_fn(toks, layers, return_contacts, lengths=None):
         if varlen and not return_contacts:
             return model.forward_varlen(toks, repr_layers=layers, lengths=lengths)
+        if return_contacts and getattr(model, "supports_contacts_only", False):
+            # only the map is kept (scripts/extract.py:104-131 never looks at "attentions" / "logits")
+            return model(toks, repr_layers=layers, contacts_only=True)
         return model(toks, repr_layers=layers, return_contacts=return_contacts)
 
     embed_fn.wants_lengths = True

@@ -32,8 +32,18 @@ enum { ESMK_F32 = 0, ESMK_F16 = 1, ESMK_BF16 = 2 };
 enum {
     ESMK_OUT_LOGITS = 1u,   /* logits [B,T,V] fp32                       (esm2.py:129)      */
     ESMK_OUT_ATTN = 2u,     /* attentions [B,L,H,T,T] fp32               (esm2.py:132-139)  */
-    ESMK_OUT_CONTACTS = 4u, /* contacts [B,T-2,T-2] fp32                 (esm2.py:140-142)  */
-    ESMK_OUT_COL_ATTN = 8u  /* esmk_msa_forward: col_attentions [B,L,H,C,R,R] fp32 (msa_transformer.py:193-194) */
+    ESMK_OUT_CONTACTS = 4u, /* contacts [B,T-2,T-2] fp32                 (esm2.py:140-142).  Together with
+                               ESMK_OUT_ATTN: computed from the attention tensor like the reference
+                               (modules.py:338-357).  WITHOUT ESMK_OUT_ATTN (predict_contacts, esm2.py:146-147):
+                               accumulated layer by layer, no [B,L,H,T,T] tensor exists (csrc/contacts.hip)        */
+    ESMK_OUT_COL_ATTN = 8u, /* esmk_msa_forward: col_attentions [B,L,H,C,R,R] fp32 (msa_transformer.py:193-194) */
+    /* `.half()` / `.bfloat16()` models return their outputs in the model dtype (esm2.py:77-144 run under
+     * nn.Module.half(); ESMFold's language-model front end does exactly that, esmfold/v1/esmfold.py:61-67,118-135,
+     * and stacks all L+1 representations).  With these flags the engine writes them in the OPERAND dtype directly
+     * instead of fp32 + a cast pass: */
+    ESMK_OUT_REPR_LOWP = 16u, /* repr_out_dev[i] are operand-dtype [B,T,E] (esmk_forward and esmk_forward_packed) */
+    ESMK_OUT_ATTN_LOWP = 32u  /* attn_out_dev is operand-dtype [B,L,H,T,T]; not together with ESMK_OUT_CONTACTS on
+                                 the materialised path (the contact kernels read fp32 maps) */
 };
 
 typedef struct esmk_model esmk_model;
@@ -93,7 +103,7 @@ int esmk_workspace_bytes(const esmk_model* m, int B, int T, uint32_t out_flags, 
  *   tokens_dev     int64 [B,T]
  *   repr_layers    host array of n_repr layer indices in [0,L]; repr_out_dev[i] fp32 [B,T,E]
  *   logits_out_dev fp32 [B,T,V]            (required iff ESMK_OUT_LOGITS)
- *   attn_out_dev   fp32 [B,L,H,T,T]        (required iff ESMK_OUT_ATTN or ESMK_OUT_CONTACTS)
+ *   attn_out_dev   fp32 [B,L,H,T,T]        (required iff ESMK_OUT_ATTN)
  *   contacts_out_dev fp32 [B,T-2,T-2]      (required iff ESMK_OUT_CONTACTS)
  */
 int esmk_forward(esmk_model* m, const void* packed_dev, const int64_t* tokens_dev, int B, int T,

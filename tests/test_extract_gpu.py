@@ -52,3 +52,32 @@ def test_extract_cli_matches_oracle(tmp_path, tpb, extra):
             assert (r["mean_representations"][l] - want.mean(0)).abs().max().item() < 2e-3
             assert (r["bos_representations"][l] - ref["representations"][l][0, 0]).abs().max().item() < 2e-3 * want.abs().max().item() + 1e-6
         assert (means["mean_representations"][L][i] - ref["representations"][L][0, 1:len(s) + 1].mean(0)).abs().max().item() < 2e-3
+
+
+def test_extract_contacts_without_attention_maps(tmp_path):
+    """--include contacts: the driver asks for ``contacts_only`` (csrc/contacts.hip), padded batches; every saved
+    map is the [n,n] crop of reference scripts/extract.py:123-124 and matches the oracle on the sequence alone."""
+    L, E, H = 3, 128, 2
+    ckpt = write_esm2_checkpoint(str(tmp_path), "esm2_synth_ct", L, E, H, seed=6)
+    g = torch.Generator().manual_seed(4)
+    aas = "LAGVSERTIDPKQNFYMHWC"
+    seqs = {f"p{i}": "".join(aas[j] for j in torch.randint(0, 20, (n,), generator=g).tolist())
+            for i, n in enumerate([40, 131, 77])}
+    fasta = tmp_path / "in.fasta"
+    fasta.write_text("".join(f">{k}\n{v}\n" for k, v in seqs.items()))
+    out_dir = tmp_path / "out"
+    env = dict(os.environ, PYTHONPATH=ROOT, TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD="1")
+    subprocess.run([sys.executable, "-m", "esm_amd.extract", ckpt, str(fasta), str(out_dir), "--repr_layers", "-1",
+                    "--include", "mean", "contacts", "--toks_per_batch", "600"], check=True, env=env, cwd=ROOT,
+                   timeout=600)
+    sd = synth_esm2_state_dict(L, E, H, seed=6)
+    from esm_amd import Alphabet
+
+    alphabet = Alphabet.from_architecture("ESM-1b")
+    for label, s in seqs.items():
+        toks = torch.tensor([[alphabet.cls_idx] + alphabet.encode(s) + [alphabet.eos_idx]])
+        ref = esm2_forward(sd, toks, L, H, repr_layers=[L], return_contacts=True)
+        r = torch.load(out_dir / f"{label}.pt", weights_only=False)
+        assert r["contacts"].shape == (len(s), len(s))
+        assert (r["contacts"] - ref["contacts"][0]).abs().max().item() < 5e-3
+        assert (r["mean_representations"][L] - ref["representations"][L][0, 1:len(s) + 1].mean(0)).abs().max().item() < 2e-3
