@@ -40,6 +40,16 @@ ESMK_DEV float row16_sum(float v) {
     return v;
 }
 
+// v[lane] + v[lane ^ 32] in every lane: v_permlane32_swap_b32 exchanges the upper half of its first operand with
+// the lower half of its second one (a VALU op; __shfl_xor goes through the LDS crossbar and an lgkmcnt wait)
+ESMK_DEV float half_swap_sum(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // residue mask of token position t of one sequence (modules.py:340-347 + the pad mask of esm2.py:135-139)
 ESMK_DEV float residue_mask(const int64_t* tok, int t, int Tlen, int pad_idx, int eos_idx, int bos, int eos) {
     if (t < bos || t >= Tlen - eos) return 0.f;
@@ -262,22 +272,26 @@ __global__ __launch_bounds__(256, 2) void contact_accum64_kernel(
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) xo[ks] = lm * 128 + (((2 * ks + hh) ^ ((lane >> 1) & 7)) << 4);
 
-    float kb2[4];  // key bias in the exp2 domain: 0, or -inf for <pad> / masked / out-of-range keys
+    // key bias (0 / -inf for <pad>), -inf for masked and out-of-range keys: the score accumulators START from it,
+    // so the MFMA chain delivers s + bias and the masking costs no VALU work
+    float kbr[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         const int key = kc + jj * 32 + lm;
         const bool keep = key < Tlen && residue_mask(tok, key, Tlen, pad_idx, eos_idx, bos, eos) != 0.f;
-        kb2[jj] = keep ? (key_bias != nullptr ? key_bias[(size_t)b * Tlen + key] * LOG2E : 0.f) : -__builtin_inff();
+        kbr[jj] = keep ? (key_bias != nullptr ? key_bias[(size_t)b * Tlen + key] : 0.f) : -__builtin_inff();
     }
     const int qr = min(q0 + lm, Tlen - 1);
     const int nblk = min(4, (Tlen - kc + 31) >> 5);
     const bool qkeep = q0 + lm < Tlen && residue_mask(tok, q0 + lm, Tlen, pad_idx, eos_idx, bos, eos) != 0.f;
 
-    f32x16 acc[4];
+    // fp32 VALU instructions take 4 cycles per wave on gfx950 (PMC: 4.5 cycles per VALU instruction in this kernel)
+    // and the packed forms process two values in the same 4: the per-score arithmetic is written on float pairs
+    f32x2 acc[4][8];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[jj][r] = 0.f;
+        for (int i = 0; i < 8; ++i) acc[jj][i] = f32x2{0.f, 0.f};
     auto load_q = [&](V8 (&qf)[4], int hd) {
         const T* qp = q + (((size_t)b * H + hd) * Tlen + qr) * 64 + 8 * hh;
 #pragma unroll
@@ -304,39 +318,43 @@ __global__ __launch_bounds__(256, 2) void contact_accum64_kernel(
             if (active) {
                 const char* sk = s_k + cur * KBUF;
                 load_q(qn, min(hd + 1, h1 - 1));
-                float cr[16], rs[16];
+                f32x2 cr[8], rs[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    cr[r] = -s_lse[(hd - hs) * 32 + mfma32_row(r, hh)];
-                    rs[r] = 0.f;
+                for (int i = 0; i < 8; ++i) {
+                    cr[i] = f32x2{-s_lse[(hd - hs) * 32 + mfma32_row(2 * i, hh)],
+                                  -s_lse[(hd - hs) * 32 + mfma32_row(2 * i + 1, hh)]};
+                    rs[i] = f32x2{0.f, 0.f};
                 }
                 const float wl = wreg[layer * H + hd];
+                const f32x2 wl2 = f32x2{wl, wl}, l2e = f32x2{LOG2E, LOG2E};
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     if (jj < nblk) {  // wave uniform
                         f32x16 s;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                        for (int r = 0; r < 16; ++r) s[r] = kbr[jj];
 #pragma unroll
                         for (int ks = 0; ks < 4; ++ks) {
                             const V8 kf = *reinterpret_cast<const V8*>(sk + jj * 4096 + xo[ks]);
                             s = Op<T>::mma(qf[ks], kf, s);
                         }
-                        float cs = 0.f;
+                        f32x2 cs2 = f32x2{0.f, 0.f};
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, cr[r]) + kb2[jj]);
-                            acc[jj][r] = __builtin_fmaf(wl, p, acc[jj][r]);
-                            rs[r] += p;
-                            cs += p;
+                        for (int i = 0; i < 8; ++i) {
+                            // exp(s + key_bias - lse); -inf stays -inf -> 0
+                            const f32x2 t = __builtin_elementwise_fma(f32x2{s[2 * i], s[2 * i + 1]}, l2e, cr[i]);
+                            const f32x2 p = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                            acc[jj][i] = __builtin_elementwise_fma(wl2, p, acc[jj][i]);
+                            rs[i] += p;
+                            cs2 += p;
                         }
-                        cs += __shfl_xor(cs, 32, 64);
+                        const float cs = half_swap_sum(cs2[0] + cs2[1]);  // the lane halves hold different query rows
                         if (hh == 0) s_col[(hd - hs) * 128 + jj * 32 + lm] = cs;
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = row16_sum(rs[r]);
+                    const float v = row16_sum(rs[r >> 1][r & 1]);
                     if ((lane & 15) == 0) s_row[((hd - hs) * 2 + ((lane >> 4) & 1)) * 32 + mfma32_row(r, hh)] = v;
                 }
 #pragma unroll
@@ -368,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void contact_accum64_kernel(
                 const int qrow = q0 + mfma32_row(r, hh);
                 if (qrow < Tlen) {
                     float* a = A + (size_t)qrow * Tlen + key;
-                    *a = (layer == 0 ? 0.f : *a) + acc[jj][r];
+                    *a = (layer == 0 ? 0.f : *a) + acc[jj][r >> 1][r & 1];
                 }
             }
         }

@@ -165,6 +165,8 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
     if (C > 1024) return fail("esmk_msa_forward: more than 1024 columns are not supported");
     if (C > m->npos - m->cfg.pad_idx - 1)
         return fail("esmk_msa_forward: sequence length above the maximum of the positional embedding");  // modules.py:243-247
+    if (out_flags & (ESMK_OUT_REPR_LOWP | ESMK_OUT_ATTN_LOWP))
+        return fail("esmk_msa_forward: outputs are fp32 (ESMK_OUT_*_LOWP is an esmk_forward flag)");
     const bool want_logits = out_flags & ESMK_OUT_LOGITS;
     const bool want_contacts = out_flags & ESMK_OUT_CONTACTS;
     const bool want_attn = (out_flags & ESMK_OUT_ATTN) || want_contacts;

@@ -25,9 +25,11 @@ def main():
     ap.add_argument("--fused", default="4,16,64")
     ap.add_argument("--materialised", default="4,16")
     ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--layers", type=int, default=0, help="override the number of layers (profiling runs)")
     args = ap.parse_args()
     name = next(k for k in ESM2_DIMS if k == args.model or k.split("_")[2] == args.model)
     L, E, H = ESM2_DIMS[name]
+    L = args.layers or L
     model = esm.ESM2(L, E, H).eval()
     model.load_state_dict(synth_esm2_state_dict(L, E, H, seed=0))
     model = model.cuda()
