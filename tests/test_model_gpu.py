@@ -142,6 +142,10 @@ def test_3b_dims_contacts_against_oracle():
     print(f"\n3B-dims: repr rel {e:.2e}; contact prob err {p0:.2e}/{p1:.2e}, logit err {z0:.2e}/{z1:.2e}")
     assert e < REL_DEEP
     assert max(p0, p1) < 2e-2 and max(z0, z1) < 1e-1, (p0, p1, z0, z1)
+    # the same map without the [2,36,40,96,96] attention tensor (csrc/contacts.hip; 1440 channels, 40 heads)
+    with torch.no_grad():
+        fused = model.predict_contacts(toks.cuda()).cpu()
+    assert (fused[0] - c[0]).abs().max().item() < 5e-5 and (fused[1, :59, :59] - c[1, :59, :59]).abs().max().item() < 5e-5
 
 
 @pytest.mark.parametrize("name", ["esm2_t6_8M_UR50D", "esm2_t12_35M_UR50D", "esm2_t30_150M_UR50D"])
