@@ -24,6 +24,9 @@ CASES = {
     "mid_d64": dict(L=3, E=256, H=4, seed=12, T=70, B=2, keep_attn=True),
     "t6_8M_dims": dict(L=6, E=320, H=20, seed=13, T=24, B=2),
     "nopad_d64": dict(L=2, E=128, H=2, seed=14, T=130, B=2, nopad=True),
+    # two 128-token blocks; row 1 carries an <eos> in the MIDDLE with residues after it (masked out of every
+    # contact channel, modules.py:340-343), row 0 ends early (eos + pads)
+    "eosmid_d64": dict(L=2, E=128, H=2, seed=15, T=150, B=2, eosmid=True),
 }
 
 
@@ -81,12 +84,20 @@ def main():
     ref = importlib.import_module("esm")
     assert ref.__file__.startswith(REFERENCE), ref.__file__
 
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]  # e.g. --only=eosmid_d64
     for name, c in CASES.items():
+        if only and name not in only:
+            continue
         sd = synth_esm2_state_dict(c["L"], c["E"], c["H"], seed=c["seed"])
         model = ref.ESM2(num_layers=c["L"], embed_dim=c["E"], attention_heads=c["H"], alphabet="ESM-1b",
                          token_dropout=True).eval()
         model.load_state_dict(sd, strict=True)
-        toks = build_tokens(c["B"], c["T"], c["seed"], c.get("nopad", False))
+        toks = build_tokens(c["B"], c["T"], c["seed"], c.get("nopad", False) or c.get("eosmid", False))
+        if c.get("eosmid"):
+            toks[1, 60] = 2
+            toks[1, 20] = 32
+            toks[0, 99] = 2
+            toks[0, 100:] = 1
         with torch.no_grad():
             out = model(toks, repr_layers=list(range(c["L"] + 1)), return_contacts=True)
         fix = {
@@ -197,5 +208,6 @@ if __name__ == "__main__":
         main_esm1b()
     else:
         main()
-        main_msa()
+        if not any(a.startswith("--only=") for a in sys.argv):
+            main_msa()
         main_esm1b()
