@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(
         }
         // ---- online softmax (fp32) ---------------------------------------------------------
         float mx;
-        if constexpr (TREE) {
+        if constexpr (TREE == 1) {
             float mx4[4];  // four independent chains instead of one 32-deep dependency chain
 #pragma unroll
             for (int c = 0; c < 4; ++c) mx4[c] = st[c >> 1][8 * (c & 1)];
@@ -247,10 +247,44 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m2, mx * LOG2E);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        V8 pf[4];
+        if constexpr (TREE == 2) {
+            // (a) fp32 VALU instructions take 4 cycles per wave on gfx950 and the PMC pass of this kernel shows the
+            // VALU, not the matrix pipe, as the busier unit (profiles/r1_v20_attention_pmc.txt): the per-score fma and
+            // the row-sum adds are written on float pairs (v_pk_fma_f32 / v_pk_add_f32: two values per 4 cycles).
+            // (b) the running maximum rarely moves after the first key tiles: when no lane's maximum grew, alpha is
+            // exactly 1 and the rescale of O^T and of the denominator is skipped — bit-identical to multiplying by 1.
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            if (__builtin_amdgcn_ballot_w64(m_new != m2) != 0) {  // wave uniform
+                const float alpha = __builtin_amdgcn_exp2f(m2 - m_use);
+                lsum *= alpha;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            }
+            m2 = m_new;
+            const f32x2 l2e = f32x2{LOG2E, LOG2E}, nm = f32x2{-m_use, -m_use};
+            f32x2 ps2 = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2 t = __builtin_elementwise_fma(
+                            f32x2{st[t2][8 * ks + e], st[t2][8 * ks + e + 1]}, l2e, nm);
+                        const f32x2 p = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                        ps2 += p;
+                        pf[2 * t2 + ks][e] = Op<T>::from(p[0]);
+                        pf[2 * t2 + ks][e + 1] = Op<T>::from(p[1]);
+                    }
+                }
+            lsum += ps2[0] + ps2[1];
+        } else {
         const float alpha = __builtin_amdgcn_exp2f(m2 - m_use);
         m2 = m_new;
         float ps4[4] = {0.f, 0.f, 0.f, 0.f};
-        V8 pf[4];
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -267,6 +301,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
         // ---- O^T += V^T . P^T ----------------------------------------------------------------
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -570,7 +605,8 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
     if (B <= 0 || H <= 0 || T <= 0 || Tp < T || (Tp & 63)) return hipErrorInvalidValue;
     const int nq = segs.work != nullptr ? n_items : (T + 127) / 128;
     dim3 grid(nq * B * H);
-    // ESMK_ATTN (read once): bit 0 XCD-grouped grid, bit 1 three LDS stages, bit 2 split reductions
+    // ESMK_ATTN (read once): bit 0 XCD-grouped grid, bit 1 three LDS stages, bit 2 split reductions,
+    // bit 3 64 query rows per wave, bit 4 four waves per SIMD, bit 5 packed softmax + lazy rescale
     static const int var = [] {
         const char* e = getenv("ESMK_ATTN");
         return e ? atoi(e) : ATTN_DEFAULT_VARIANT;
@@ -579,7 +615,9 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
     hipLaunchKernelGGL((attn_fwd_kernel<TT, ST, TR>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k, \
                        (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad, segs)
 #define ESMK_ATTN_VARIANTS(TT)                                   \
-    if (var & 16) {  /* <= 128 VGPRs: four waves per SIMD */     \
+    if (var & 32) {  /* packed softmax arithmetic + rescale only when a maximum grew */ \
+        ESMK_ATTN_LAUNCH(TT, 2, 2);                              \
+    } else if (var & 16) {  /* <= 128 VGPRs: four waves per SIMD */     \
         hipLaunchKernelGGL((attn_fwd_kernel<TT, 2, 0, 4>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k, \
                            (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad, segs); \
     } else                                                       \

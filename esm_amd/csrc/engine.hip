@@ -886,6 +886,24 @@ int esmk_op_linear(const void* a_dev, const void* w_dev, const float* bias_dev, 
     return 0;
 }
 
+int esmk_debug_linear_splitk(const void* a_dev, const void* w_dev, float* partials_dev, int M, int N, int K,
+                             int S, int operand_dtype, void* stream) {
+    if (S < 1 || K % S != 0 || (K / S) % 64 != 0) return fail("esmk_debug_linear_splitk: K/S must be a multiple of 64");
+    GemmArgs g;
+    g.A = a_dev;
+    g.W = w_dev;
+    g.out = partials_dev;
+    g.M = M;
+    g.N = N;
+    g.K = K / S;
+    g.a_row_bytes = g.w_row_bytes = (long long)K * 2;  // rows keep the full-K stride
+    g.batch = S;
+    g.a_bo = g.w_bo = (long long)(K / S) * 2;           // slice s starts K/S operand elements further right
+    g.o_bo = (long long)M * N * 4;
+    ESMK_TRY(launch_gemm(g, EPI_STORE_F32, operand_dtype, (hipStream_t)stream));
+    return 0;
+}
+
 int esmk_debug_gemm_timing(void* stamps_dev) {
     gemm8_set_timing((unsigned long long*)stamps_dev);
     return 0;

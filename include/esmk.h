@@ -195,6 +195,12 @@ int esmk_op_layernorm(const float* x_dev, const float* gamma_dev, const float* b
 int esmk_op_linear(const void* a_dev, const void* w_dev, const float* bias_dev, void* out_dev,
                    int M, int N, int K, int epilogue, int operand_dtype, void* stream);
 
+/* Measurement hook (no reference counterpart; tools/bench_splitk.py): S fp32 partial products
+ * out[s][M,N] = A[:, sK/S:(s+1)K/S] . W[:, sK/S:(s+1)K/S]^T as ONE batched launch of the persistent kernel
+ * (K/S a multiple of 64).  Small-batch study: a [4096,5120]x[1280,5120] GEMM has 80 tiles for 256 CUs. */
+int esmk_debug_linear_splitk(const void* a_dev, const void* w_dev, float* partials_dev, int M, int N, int K,
+                             int S, int operand_dtype, void* stream);
+
 /* Measurement hook (no reference counterpart): when stamps_dev != NULL every following persistent
  * GEMM launch records s_memtime stamps per workgroup and tile, uint64 [256][32][4] =
  * {tile start, main loop done, epilogue done, unused}; NULL switches it off. */
