@@ -162,3 +162,62 @@ def test_pack_plan_layout():
     assert torch.equal(keep, torch.arange(6).unsqueeze(0) < plan.lengths.unsqueeze(1))
     assert torch.equal(back[keep], toks[keep]) and int(back[~keep].abs().sum()) == 0
     assert pack_plan(toks, 1, lengths=[6, 6, 6]).segments.tolist() == [[0, 6], [16, 6], [32, 6]]
+
+
+def test_predict_contacts_refuses_cpu_tensors():
+    """predict_contacts (reference esm2.py:146-147) takes the contacts-only engine path; like forward it has no CPU
+    fallback."""
+    m = esm.ESM2(1, 128, 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.predict_contacts(torch.tensor([[0, 5, 6, 2]]))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.tensor([[0, 5, 6, 2]]), contacts_only=True)
+
+
+def test_native_lowp_rule(monkeypatch):
+    """Model-dtype outputs are written by the engine only when the model dtype IS the operand dtype."""
+    from esm_amd.esm2 import _native_lowp, _operand_dtype_for
+
+    monkeypatch.delenv("ESM_AMD_NATIVE_LOWP", raising=False)
+    monkeypatch.delenv("ESM_AMD_OPERAND", raising=False)
+    assert _operand_dtype_for(torch.float32) == torch.float16 and _operand_dtype_for(torch.bfloat16) == torch.bfloat16
+    assert _native_lowp(torch.float16, torch.float16) and _native_lowp(torch.bfloat16, torch.bfloat16)
+    assert not _native_lowp(torch.float32, torch.float16)   # fp32 model: fp32 outputs
+    assert not _native_lowp(torch.float16, torch.bfloat16)  # .half() model forced to bf16 operands: cast outside
+    monkeypatch.setenv("ESM_AMD_NATIVE_LOWP", "0")
+    assert not _native_lowp(torch.float16, torch.float16)
+
+
+def test_extract_embed_fn_dispatch():
+    """esm_amd.extract.make_embed_fn: token-packed forward without contacts, the contacts-only forward (no attention
+    tensor) with contacts, the reference-shaped call for models that have neither (MSA Transformer)."""
+    from esm_amd.extract import make_embed_fn
+
+    calls = []
+
+    class Engine:
+        supports_varlen = True
+        supports_contacts_only = True
+
+        def forward_varlen(self, toks, repr_layers, lengths=None):
+            calls.append(("varlen", tuple(repr_layers), lengths))
+            return {}
+
+        def __call__(self, toks, repr_layers, return_contacts=False, contacts_only=False):
+            calls.append(("forward", tuple(repr_layers), return_contacts, contacts_only))
+            return {}
+
+    class Plain:
+        def __call__(self, toks, repr_layers, return_contacts=False):
+            calls.append(("plain", tuple(repr_layers), return_contacts))
+            return {}
+
+    toks = torch.zeros((2, 5), dtype=torch.int64)
+    fn = make_embed_fn(Engine())
+    assert fn.wants_lengths
+    fn(toks, [3], False, lengths=[5, 4])
+    fn(toks, [3], True, lengths=[5, 4])
+    make_embed_fn(Engine(), varlen=False)(toks, [3], False)
+    make_embed_fn(Plain())(toks, [1], True)
+    assert calls == [("varlen", (3,), [5, 4]), ("forward", (3,), False, True), ("forward", (3,), False, False),
+                     ("plain", (1,), True)]
