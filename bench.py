@@ -33,6 +33,56 @@ MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_M
 HBM_PEAK_GBS = 8000.0
 
 
+def timed_steps(step, steps, warmup, sync_all, dist, dev):
+    """The contract's timed region: `warmup` untimed steps, then exactly `steps` steps bracketed by
+    synchronise + barrier on both sides; returns the MAX elapsed seconds over ranks."""
+    for _ in range(warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def protocol_test(args):
+    """Same rank / world handling, barriers, MAX-over-ranks and single JSON line as the real run, on CPU with the
+    gloo backend and a stub step that takes 5 ms x (rank + 1): there is no GPU in the build container and the 8-GPU
+    run belongs to the driver, so this is what keeps the N > 1 path honest."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+
+    elapsed = timed_steps(lambda: time.sleep(0.005 * (rank + 1)), args.steps, args.warmup, sync_all, dist, dev)
+    if rank == 0:
+        print(json.dumps({"metric": "protocol-test (not a measurement)", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+                          "value": round(world * args.batch * args.seq_len * args.steps / elapsed, 1),
+                          "scaling": "weak"}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -42,7 +92,12 @@ def main():
     ap.add_argument("--seq-len", type=int, default=1022)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2, help="sequences in the CPU baseline sample")
+    ap.add_argument("--protocol-test", action="store_true",
+                    help="CPU/gloo dry run of the launch + timing protocol with a stub step (tests/test_bench_protocol.py); "
+                         "never a measurement")
     args = ap.parse_args()
+    if args.protocol_test:
+        return protocol_test(args)
 
     import esm
     from esm_amd.synth import ESM2_DIMS, synth_esm2_state_dict, synth_tokens
@@ -80,21 +135,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            out = model(toks, repr_layers=[L])
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = model(toks, repr_layers=[L])
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        elapsed = timed_steps(lambda: model(toks, repr_layers=[L]), args.steps, args.warmup, sync_all, dist, dev)
 
         # per-kernel-class timing with HIP events (separate steps so the timed region is unperturbed)
         prof_steps = 2

@@ -1,0 +1,34 @@
+"""bench.py's launch + timing protocol at world_size 2 on CPU (gloo): rank / world handling from the
+torch.distributed.run environment, barrier-bracketed timed region, MAX over ranks, ONE JSON line from rank 0.
+The step is a stub (5 ms x (rank + 1)); the real step needs an MI355X (tests -m gpu, bench.py itself)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_protocol(tmp_path):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "1", "--protocol-test"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout  # rank 0 only
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["warmup"] == 1 and r["scaling"] == "weak"
+    # rank 1's steps take 10 ms: the MAX over ranks is reported, not rank 0's own 5 ms
+    assert 9.5 <= r["ms_per_step"] < 60, r
+    assert abs(r["value"] - 2 * 64 * 1022 * 4 / (r["ms_per_step"] * 4e-3)) / r["value"] < 1e-3
+
+
+def test_single_process_protocol():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "0",
+                          "--protocol-test"], capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=ROOT),
+                         timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 1 and 4.5 <= r["ms_per_step"] < 40
