@@ -1,0 +1,133 @@
+"""Live differential tests against the reference implementation itself — only where /root/reference is mounted
+(the build container; skipped on the GPU box, where the committed fixtures of tests/golden/ take over).
+
+The reference package is also called ``esm``, so it runs in a SUBPROCESS (tests/_reference_probe.py) that dumps
+what the reference computes for seeded random inputs; this process then compares
+  * the host side (esm_amd.Alphabet / BatchConverter / MSABatchConverter / FastaBatchedDataset.get_batch_indices /
+    read_fasta) — integer work, bit-exact — with reference esm/data.py:19-378;
+  * the oracles (oracle/esm2_oracle.py, esm1b_oracle.py, msa_oracle.py) with reference ESM2 / ProteinBertModel /
+    MSATransformer forwards on synthetic weights at dims and seeds that are NOT among the committed fixtures
+    (head dims 24 / 32 / 128, other depths), to <= 2e-5: the pin of the oracle is re-checked wherever the reference
+    is available, not only on the frozen vectors.
+"""
+import os
+import pickle
+import subprocess
+import sys
+
+import pytest
+import torch
+
+REFERENCE = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "esm")),
+                                reason="/root/reference is not mounted here")
+
+
+@pytest.fixture(scope="module")
+def probe(tmp_path_factory):
+    out = tmp_path_factory.mktemp("refprobe") / "probe.pkl"
+    env = dict(os.environ, TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD="1")
+    env.pop("PYTHONPATH", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_reference_probe.py"), str(out)],
+                       capture_output=True, text=True, env=env, cwd=str(out.parent), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    with open(out, "rb") as f:
+        return pickle.load(f)
+
+
+def test_tokenizer_and_batch_converter_bit_exact(probe):
+    import esm
+
+    for arch, cases in probe["alphabet"].items():
+        a = esm.Alphabet.from_architecture(arch)
+        assert a.all_toks == cases["all_toks"], arch
+        assert (a.padding_idx, a.cls_idx, a.eos_idx, a.unk_idx, a.mask_idx) == cases["ids"], arch
+        assert (a.prepend_bos, a.append_eos) == cases["bos_eos"], arch
+        for s, want in cases["encode"]:
+            assert a.encode(s) == want, (arch, s)
+        for s, want in cases["tokenize"]:
+            assert a.tokenize(s) == want, (arch, s)
+        for trunc, batch, (labels, strs, toks) in cases["batches"]:
+            got = a.get_batch_converter(trunc)(batch)
+            assert got[0] == labels and got[1] == strs, (arch, trunc)
+            assert got[2].dtype == torch.int64 and torch.equal(got[2], toks), (arch, trunc)
+        for s in cases["raises"]:
+            with pytest.raises(KeyError):
+                a.encode(s)
+
+
+def test_msa_batch_converter_bit_exact(probe):
+    import esm
+
+    a = esm.Alphabet.from_architecture("msa_transformer")
+    conv = a.get_batch_converter()
+    for inp, (labels, strs, toks) in probe["msa_batches"]:
+        got = conv(inp)
+        assert got[0] == labels and got[1] == strs and torch.equal(got[2], toks)
+    with pytest.raises(RuntimeError, match="unaligned"):
+        conv([("a", "MKT"), ("b", "MK")])
+
+
+def test_fasta_dataset_and_batching_bit_exact(probe, tmp_path):
+    import esm
+
+    for text, toks_per_batch, extra, (labels, seqs, batches) in probe["fasta"]:
+        f = tmp_path / "x.fasta"
+        f.write_text(text)
+        ds = esm.FastaBatchedDataset.from_file(f)
+        assert list(ds.sequence_labels) == labels and list(ds.sequence_strs) == seqs
+        assert ds.get_batch_indices(toks_per_batch, extra_toks_per_seq=extra) == batches
+    for path, kw, rows in probe["read_fasta"]:
+        assert list(esm.data.read_fasta(path, **kw))[:len(rows)] == rows, kw
+
+
+def _close(a, b, tol, mask=None):
+    d = (a - b).abs()
+    if mask is not None:
+        d = d[mask]
+    return d.numel() == 0 or d.max().item() <= tol
+
+
+def test_esm2_oracle_matches_live_reference(probe):
+    from esm_amd.synth import synth_esm2_state_dict
+    from oracle.esm2_oracle import esm2_forward
+
+    for c in probe["esm2"]:
+        sd = synth_esm2_state_dict(c["L"], c["E"], c["H"], seed=c["seed"])
+        out = esm2_forward(sd, c["tokens"], c["L"], c["H"], repr_layers=range(c["L"] + 1), return_contacts=True)
+        nonpad = c["tokens"].ne(1)
+        tag = (c["L"], c["E"], c["H"])
+        assert _close(out["logits"], c["logits"], 2e-5, nonpad), tag
+        for l, ref in c["representations"].items():
+            assert _close(out["representations"][l], ref, 2e-5, nonpad), (tag, l)
+        assert _close(out["attentions"], c["attentions"], 2e-6), tag
+        assert _close(out["contacts"], c["contacts"], 2e-5), tag
+
+
+def test_esm1b_oracle_matches_live_reference(probe):
+    from esm_amd.synth import synth_esm1b_state_dict
+    from oracle.esm1b_oracle import esm1b_forward
+
+    for c in probe["esm1b"]:
+        sd = synth_esm1b_state_dict(c["L"], c["E"], c["H"], seed=c["seed"], ln_before=c["ln_before"])
+        out = esm1b_forward(sd, c["tokens"], c["L"], c["H"], repr_layers=range(c["L"] + 1))
+        nonpad = c["tokens"].ne(1)
+        assert _close(out["logits"], c["logits"], 2e-5, nonpad)
+        for l, ref in c["representations"].items():
+            assert _close(out["representations"][l], ref, 2e-5, nonpad), l
+
+
+def test_msa_oracle_matches_live_reference(probe):
+    from esm_amd.synth import synth_msa_state_dict
+    from oracle.msa_oracle import msa_forward
+
+    for c in probe["msa"]:
+        sd = synth_msa_state_dict(c["L"], c["E"], c["H"], c["F"], seed=c["seed"])
+        out = msa_forward(sd, c["tokens"], c["L"], c["H"], repr_layers=range(c["L"] + 1), return_contacts=True)
+        nonpad = c["tokens"].ne(1)
+        assert _close(out["logits"], c["logits"], 5e-5, nonpad)
+        for l, ref in c["representations"].items():
+            assert _close(out["representations"][l], ref, 5e-5, nonpad), l
+        assert _close(out["row_attentions"], c["row_attentions"], 5e-6)
+        assert _close(out["contacts"], c["contacts"], 5e-5)
