@@ -131,3 +131,38 @@ def test_msa_oracle_matches_live_reference(probe):
             assert _close(out["representations"][l], ref, 5e-5, nonpad), l
         assert _close(out["row_attentions"], c["row_attentions"], 5e-6)
         assert _close(out["contacts"], c["contacts"], 5e-5)
+
+
+def test_reference_extract_script_runs_unmodified_against_the_shim(tmp_path):
+    """BASELINE configs[0]: the reference's scripts/extract.py (8M dims, examples FASTA, --nogpu), once inside the
+    reference package and once — the SAME unmodified file — against this repo's ``esm`` package.  The shim run has the
+    engine replaced by the oracle inside the test launcher only (tests/_run_reference_script.py): the product has no
+    CPU path.  Same files, same labels, same shapes, values to oracle precision."""
+    from esm_amd.synth import write_esm2_checkpoint
+
+    ckpt = write_esm2_checkpoint(str(tmp_path), "esm2_t6_8M_UR50D", 6, 320, 20, seed=7)
+    fasta = os.path.join(REFERENCE, "examples", "data", "few_proteins.fasta")
+    script = os.path.join(REFERENCE, "scripts", "extract.py")
+    args = [ckpt, fasta, "OUT", "--repr_layers", "0", "5", "6", "--include", "mean", "per_tok", "bos", "contacts",
+            "--nogpu", "--toks_per_batch", "2048"]
+    env = dict(os.environ, TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD="1")
+    outs = {}
+    for tag, cmd, pp in (("ref", [sys.executable, script], REFERENCE),
+                         ("shim", [sys.executable, os.path.join(ROOT, "tests", "_run_reference_script.py"), script], ROOT)):
+        out_dir = tmp_path / tag
+        a = [x if x != "OUT" else str(out_dir) for x in args]
+        r = subprocess.run(cmd + a, capture_output=True, text=True, env=dict(env, PYTHONPATH=pp), cwd=str(tmp_path),
+                           timeout=900)
+        assert r.returncode == 0, (tag, r.stderr[-3000:])
+        outs[tag] = {p.name: torch.load(p, weights_only=False) for p in sorted(out_dir.glob("*.pt"))}
+    assert outs["ref"] and sorted(outs["ref"]) == sorted(outs["shim"])
+    for name, ref in outs["ref"].items():
+        got = outs["shim"][name]
+        assert got["label"] == ref["label"] and sorted(got) == sorted(ref)
+        for key in ("representations", "mean_representations", "bos_representations"):
+            assert sorted(got[key]) == sorted(ref[key]) == [0, 5, 6]
+            for l in ref[key]:
+                assert got[key][l].shape == ref[key][l].shape and got[key][l].dtype == ref[key][l].dtype
+                assert (got[key][l] - ref[key][l]).abs().max().item() < 5e-5, (name, key, l)
+        assert got["contacts"].shape == ref["contacts"].shape
+        assert (got["contacts"] - ref["contacts"]).abs().max().item() < 5e-5
