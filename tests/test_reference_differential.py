@@ -166,3 +166,20 @@ def test_reference_extract_script_runs_unmodified_against_the_shim(tmp_path):
                 assert (got[key][l] - ref[key][l]).abs().max().item() < 5e-5, (name, key, l)
         assert got["contacts"].shape == ref["contacts"].shape
         assert (got["contacts"] - ref["contacts"]).abs().max().item() < 5e-5
+
+
+def test_reference_own_alphabet_tests_pass_on_our_alphabets():
+    """The reference's OWN test helpers (tests/test_alphabet.py:6-45, loaded by file path — they import nothing at
+    module level) executed on this repo's Alphabet objects; their public wrappers download checkpoints just to get an
+    alphabet, which ``Alphabet.from_architecture`` provides offline (esm/pretrained.py:87-127 picks the same names)."""
+    import importlib.util
+
+    import esm
+
+    spec = importlib.util.spec_from_file_location("ref_test_alphabet", os.path.join(REFERENCE, "tests", "test_alphabet.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for arch in ("ESM-1b", "roberta_large"):  # esm1b_t33_650M_UR50S / esm1v_t33_650M_UR90S_* use this alphabet
+        a = esm.Alphabet.from_architecture(arch)
+        mod._test_esm1b(a)
+        mod._test_esm1b_truncation(a)
