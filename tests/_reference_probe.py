@@ -171,6 +171,43 @@ def main():
                                representations={k: v.float() for k, v in o["representations"].items()},
                                row_attentions=o["row_attentions"].float(), contacts=o["contacts"].float()))
 
+    # ---- checkpoint files in the released formats, loaded by the reference's esm.pretrained -----------------
+    ck_dir = os.path.join(os.path.dirname(os.path.abspath(out_path)), "ckpt")
+    os.makedirs(ck_dir, exist_ok=True)
+    res["checkpoints"] = []
+
+    def split_regression(sd):
+        reg = {k: v for k, v in sd.items() if k.startswith("contact_head.")}
+        body = {k: v for k, v in sd.items() if not k.startswith("contact_head.")}
+        return body, reg
+
+    def record(path):
+        model, alphabet = esm.pretrained.load_model_and_alphabet(path)
+        res["checkpoints"].append(dict(path=path, cls=type(model).__name__, all_toks=list(alphabet.all_toks),
+                                       state={k: v.clone() for k, v in model.state_dict().items()},
+                                       num_layers=model.num_layers))
+
+    # ESM-2 (cfg format, esm/pretrained.py:164-188)
+    record(synth.write_esm2_checkpoint(ck_dir, "esm2_t3_synth_UR50D", 3, 128, 2, seed=201))
+    # ESM-1b (fairseq args format with encoder_* argument names and encoder.sentence_encoder.* keys, :87-99)
+    body, reg = split_regression(synth.synth_esm1b_state_dict(2, 128, 2, seed=202, ln_before=True))
+    args = argparse.Namespace(arch="roberta_large", encoder_layers=2, encoder_embed_dim=128, encoder_ffn_embed_dim=512,
+                              encoder_attention_heads=2, max_positions=1024, token_dropout=True)
+    path = os.path.join(ck_dir, "esm1b_t2_synth_UR50S.pt")
+    torch.save({"args": args, "model": {"encoder.sentence_encoder." + k: v for k, v in body.items()}}, path)
+    torch.save({"model": reg}, path[:-3] + "-contact-regression.pt")
+    record(path)
+    # MSA Transformer (args format; released files have row / column swapped in the key names, :109-121)
+    body, reg = split_regression(synth.synth_msa_state_dict(2, 128, 2, 256, seed=203))
+    swap = lambda s: s.replace("row", "column") if "row" in s else s.replace("column", "row")
+    args = argparse.Namespace(arch="msa_transformer", encoder_layers=2, encoder_embed_dim=128, encoder_ffn_embed_dim=256,
+                              encoder_attention_heads=2, dropout=0.1, attention_dropout=0.1, activation_dropout=0.1,
+                              max_positions=1024, embed_positions_msa=True, max_tokens=2 ** 14, max_tokens_per_msa=2 ** 14)
+    path = os.path.join(ck_dir, "esm_msa1b_t2_synth_UR50S.pt")
+    torch.save({"args": args, "model": {"encoder.sentence_encoder." + swap(k): v for k, v in body.items()}}, path)
+    torch.save({"model": reg}, path[:-3] + "-contact-regression.pt")
+    record(path)
+
     with open(out_path, "wb") as f:
         pickle.dump(res, f)
 

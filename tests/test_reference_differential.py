@@ -183,3 +183,21 @@ def test_reference_own_alphabet_tests_pass_on_our_alphabets():
         a = esm.Alphabet.from_architecture(arch)
         mod._test_esm1b(a)
         mod._test_esm1b_truncation(a)
+
+
+def test_checkpoint_loading_matches_reference(probe):
+    """esm.pretrained.load_model_and_alphabet on checkpoint FILES in the released formats (ESM-2 cfg format;
+    ESM-1b / MSA Transformer fairseq-args formats with encoder_* argument names, encoder.sentence_encoder.* key
+    prefixes, the row/column key swap of the MSA files, sibling -contact-regression.pt): same model class name, same
+    alphabet, same state-dict keys, identical tensors as the reference's loader (esm/pretrained.py:52-221)."""
+    import esm
+
+    assert len(probe["checkpoints"]) == 3
+    for c in probe["checkpoints"]:
+        model, alphabet = esm.pretrained.load_model_and_alphabet(c["path"])
+        assert type(model).__name__ == c["cls"], c["path"]
+        assert list(alphabet.all_toks) == c["all_toks"] and model.num_layers == c["num_layers"]
+        got = model.state_dict()
+        assert sorted(got) == sorted(c["state"]), set(got) ^ set(c["state"])
+        for k, v in c["state"].items():
+            assert got[k].dtype == v.dtype and torch.equal(got[k], v), (c["path"], k)
