@@ -208,6 +208,22 @@ def main():
     torch.save({"model": reg}, path[:-3] + "-contact-regression.pt")
     record(path)
 
+    # ---- nn.Module surface of a freshly constructed model (SURVEY.md §8 b) --------------------------------------
+    def surface(m, attrs):
+        return dict(children=[n for n, _ in m.named_children()], state_keys=list(m.state_dict().keys()),
+                    param_names=[n for n, _ in m.named_parameters()], buffer_names=[n for n, _ in m.named_buffers()],
+                    n_params=sum(p.numel() for p in m.parameters()),
+                    shapes={k: tuple(v.shape) for k, v in m.state_dict().items()},
+                    attrs={a: getattr(m, a) for a in attrs},
+                    layer_children=[n for n, _ in m.layers[0].named_children()])
+
+    scalar_attrs = ["num_layers", "embed_dim", "attention_heads", "alphabet_size", "padding_idx", "mask_idx", "cls_idx",
+                    "eos_idx", "prepend_bos", "append_eos", "token_dropout", "embed_scale"]
+    res["surface"] = {
+        "esm2_8M": surface(esm.ESM2(6, 320, 20), scalar_attrs),
+        "esm2_default": {"attrs": {a: getattr(esm.ESM2(num_layers=1), a) for a in ("embed_dim", "attention_heads")}},
+    }
+
     with open(out_path, "wb") as f:
         pickle.dump(res, f)
 

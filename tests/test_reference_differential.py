@@ -201,3 +201,25 @@ def test_checkpoint_loading_matches_reference(probe):
         assert sorted(got) == sorted(c["state"]), set(got) ^ set(c["state"])
         for k, v in c["state"].items():
             assert got[k].dtype == v.dtype and torch.equal(got[k], v), (c["path"], k)
+
+
+def test_module_surface_matches_reference(probe):
+    """What callers poke at on the nn.Module (scripts/extract.py:65-84, esmfold.py:61-67, the FSDP example wrapping
+    ``model.layers``): child-module names and order, state-dict key order and shapes, parameter / buffer names,
+    parameter count, the scalar attributes — identical to a freshly constructed reference ESM2 (esm2.py:15-75)."""
+    import esm
+
+    ref = probe["surface"]["esm2_8M"]
+    m = esm.ESM2(6, 320, 20)
+    assert [n for n, _ in m.named_children()] == ref["children"]
+    assert list(m.state_dict().keys()) == ref["state_keys"]
+    assert [n for n, _ in m.named_parameters()] == ref["param_names"]
+    assert [n for n, _ in m.named_buffers()] == ref["buffer_names"]
+    assert sum(p.numel() for p in m.parameters()) == ref["n_params"]
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == ref["shapes"]
+    assert [n for n, _ in m.layers[0].named_children()] == ref["layer_children"]
+    for a, v in ref["attrs"].items():
+        assert getattr(m, a) == v, a
+    d = esm.ESM2(num_layers=1)
+    for a, v in probe["surface"]["esm2_default"]["attrs"].items():
+        assert getattr(d, a) == v, a
