@@ -159,6 +159,9 @@ class MSATransformer(nn.Module):
             self.msa_position_embedding = nn.Parameter(0.01 * torch.randn(1, 1024, 1, emb_dim), requires_grad=True)
         else:
             self.register_parameter("msa_position_embedding", None)
+        # reference msa_transformer.py:114: a parameter-less child kept for the module surface (named_children order);
+        # the engine is forward-only and refuses training mode with non-zero dropout (see forward)
+        self.dropout_module = nn.Dropout(getattr(args, "dropout", 0.0))
         mtpm = getattr(args, "max_tokens_per_msa", getattr(args, "max_tokens", 2 ** 14))
         self.layers = nn.ModuleList(
             [AxialTransformerLayer(E, args.ffn_embed_dim, args.attention_heads, mtpm) for _ in range(args.layers)])

@@ -219,7 +219,19 @@ def main():
 
     scalar_attrs = ["num_layers", "embed_dim", "attention_heads", "alphabet_size", "padding_idx", "mask_idx", "cls_idx",
                     "eos_idx", "prepend_bos", "append_eos", "token_dropout", "embed_scale"]
+    msa_args = argparse.Namespace(layers=2, embed_dim=96, ffn_embed_dim=192, attention_heads=3, dropout=0.1,
+                                  attention_dropout=0.1, activation_dropout=0.1, max_positions=1024,
+                                  embed_positions_msa=True, embed_positions_msa_dim=96, max_tokens=2 ** 14,
+                                  max_tokens_per_msa=2 ** 14)
+    b_args = argparse.Namespace(arch="roberta_large", layers=2, embed_dim=96, ffn_embed_dim=384, attention_heads=3,
+                                max_positions=1024, token_dropout=True, emb_layer_norm_before=True)
     res["surface"] = {
+        "msa": surface(esm.MSATransformer(msa_args, esm.Alphabet.from_architecture("msa_transformer")),
+                       ["num_layers", "padding_idx", "mask_idx", "cls_idx", "eos_idx", "prepend_bos", "append_eos",
+                        "alphabet_size"]),
+        "esm1b": surface(esm.ProteinBertModel(b_args, esm.Alphabet.from_architecture("roberta_large")),
+                         ["num_layers", "padding_idx", "mask_idx", "cls_idx", "eos_idx", "prepend_bos", "append_eos",
+                          "alphabet_size", "model_version"]),
         "esm2_8M": surface(esm.ESM2(6, 320, 20), scalar_attrs),
         "esm2_default": {"attrs": {a: getattr(esm.ESM2(num_layers=1), a) for a in ("embed_dim", "attention_heads")}},
     }

@@ -223,3 +223,31 @@ def test_module_surface_matches_reference(probe):
     d = esm.ESM2(num_layers=1)
     for a, v in probe["surface"]["esm2_default"]["attrs"].items():
         assert getattr(d, a) == v, a
+
+
+def _check_surface(m, ref):
+    assert [n for n, _ in m.named_children()] == ref["children"]
+    assert list(m.state_dict().keys()) == ref["state_keys"]
+    assert [n for n, _ in m.named_parameters()] == ref["param_names"]
+    assert [n for n, _ in m.named_buffers()] == ref["buffer_names"]
+    assert sum(p.numel() for p in m.parameters()) == ref["n_params"]
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == ref["shapes"]
+    assert [n for n, _ in m.layers[0].named_children()] == ref["layer_children"]
+    for a, v in ref["attrs"].items():
+        assert getattr(m, a) == v, a
+
+
+def test_msa_and_esm1b_module_surface_matches_reference(probe):
+    """Same check for MSATransformer (msa_transformer.py:20-144) and ProteinBertModel / ESM-1b (esm1.py:20-115)."""
+    import argparse
+
+    import esm
+
+    msa_args = argparse.Namespace(layers=2, embed_dim=96, ffn_embed_dim=192, attention_heads=3, dropout=0.1,
+                                  attention_dropout=0.1, activation_dropout=0.1, max_positions=1024,
+                                  embed_positions_msa=True, embed_positions_msa_dim=96, max_tokens=2 ** 14,
+                                  max_tokens_per_msa=2 ** 14)
+    _check_surface(esm.MSATransformer(msa_args, esm.Alphabet.from_architecture("msa_transformer")), probe["surface"]["msa"])
+    b_args = argparse.Namespace(arch="roberta_large", layers=2, embed_dim=96, ffn_embed_dim=384, attention_heads=3,
+                                max_positions=1024, token_dropout=True, emb_layer_norm_before=True)
+    _check_surface(esm.ProteinBertModel(b_args, esm.Alphabet.from_architecture("roberta_large")), probe["surface"]["esm1b"])
