@@ -208,6 +208,40 @@ def main():
     torch.save({"model": reg}, path[:-3] + "-contact-regression.pt")
     record(path)
 
+    # ---- Alphabet object surface + dataset edge cases (esm/data.py:91-297, 24-88) -------------------------------
+    res["alphabet_surface"] = {}
+    for arch in ("ESM-1b", "roberta_large", "ESM-1", "msa_transformer", "invariant_gvp"):
+        a = esm.Alphabet.from_architecture(arch)
+        fields = ("standard_toks", "prepend_toks", "append_toks", "prepend_bos", "append_eos", "use_msa", "all_toks",
+                  "tok_to_idx", "unk_idx", "padding_idx", "cls_idx", "mask_idx", "eos_idx", "all_special_tokens",
+                  "unique_no_split_tokens")
+        res["alphabet_surface"][arch] = dict(
+            fields={f: getattr(a, f) for f in fields}, length=len(a), to_dict=a.to_dict(),
+            get_idx=[(t, a.get_idx(t)) for t in ("L", "J", "<mask>", "<cls>", "-", "nonsense")],
+            get_tok=[(i, a.get_tok(i)) for i in (0, 1, 5, len(a) - 1)],
+            converter=type(a.get_batch_converter()).__name__)
+    try:
+        esm.Alphabet.from_architecture("no_such_arch")
+        res["alphabet_surface"]["_invalid"] = None
+    except Exception as e:  # noqa: BLE001
+        res["alphabet_surface"]["_invalid"] = type(e).__name__
+    ds = esm.FastaBatchedDataset(["a", "b", "c"], ["MKT", "MKTVRQG", "M"])
+    res["dataset"] = dict(length=len(ds), items=[ds[i] for i in range(3)], batches=ds.get_batch_indices(8, 1))
+    import tempfile as _tf
+
+    with _tf.NamedTemporaryFile("w", suffix=".fasta", delete=False) as f:
+        f.write(">x\nMK\n>x\nMKT\n")
+        dup = f.name
+    try:
+        esm.FastaBatchedDataset.from_file(dup)
+        res["dataset"]["duplicate_labels"] = None
+    except Exception as e:  # noqa: BLE001
+        res["dataset"]["duplicate_labels"] = (type(e).__name__, str(e))
+    os.unlink(dup)
+    a = esm.Alphabet.from_architecture("ESM-1b")
+    labels, strs, toks = a.get_batch_converter()([("e", ""), ("f", "MK")])
+    res["dataset"]["empty_string_batch"] = (labels, strs, toks)
+
     # ---- nn.Module surface of a freshly constructed model (SURVEY.md §8 b) --------------------------------------
     def surface(m, attrs):
         return dict(children=[n for n, _ in m.named_children()], state_keys=list(m.state_dict().keys()),

@@ -251,3 +251,36 @@ def test_msa_and_esm1b_module_surface_matches_reference(probe):
     b_args = argparse.Namespace(arch="roberta_large", layers=2, embed_dim=96, ffn_embed_dim=384, attention_heads=3,
                                 max_positions=1024, token_dropout=True, emb_layer_norm_before=True)
     _check_surface(esm.ProteinBertModel(b_args, esm.Alphabet.from_architecture("roberta_large")), probe["surface"]["esm1b"])
+
+
+def test_alphabet_object_and_dataset_edge_cases(probe, tmp_path):
+    """Attributes and small methods of Alphabet for all five architectures the reference names (data.py:91-176), the
+    error for an unknown architecture, FastaBatchedDataset indexing, the duplicate-label check of from_file
+    (data.py:52-55) and a batch holding an empty string."""
+    import esm
+
+    for arch, ref in probe["alphabet_surface"].items():
+        if arch == "_invalid":
+            continue
+        a = esm.Alphabet.from_architecture(arch)
+        for f, v in ref["fields"].items():
+            assert getattr(a, f) == v, (arch, f)
+        assert len(a) == ref["length"] and a.to_dict() == ref["to_dict"]
+        assert [(t, a.get_idx(t)) for t, _ in ref["get_idx"]] == ref["get_idx"], arch
+        assert [(i, a.get_tok(i)) for i, _ in ref["get_tok"]] == ref["get_tok"], arch
+        assert type(a.get_batch_converter()).__name__ == ref["converter"], arch
+    with pytest.raises(Exception) as ei:
+        esm.Alphabet.from_architecture("no_such_arch")
+    assert type(ei.value).__name__ == probe["alphabet_surface"]["_invalid"]
+    ds = esm.FastaBatchedDataset(["a", "b", "c"], ["MKT", "MKTVRQG", "M"])
+    ref = probe["dataset"]
+    assert len(ds) == ref["length"] and [ds[i] for i in range(3)] == ref["items"]
+    assert ds.get_batch_indices(8, 1) == ref["batches"]
+    f = tmp_path / "dup.fasta"
+    f.write_text(">x\nMK\n>x\nMKT\n")
+    with pytest.raises(Exception) as ei:
+        esm.FastaBatchedDataset.from_file(f)
+    assert (type(ei.value).__name__, str(ei.value)) == ref["duplicate_labels"]
+    a = esm.Alphabet.from_architecture("ESM-1b")
+    labels, strs, toks = a.get_batch_converter()([("e", ""), ("f", "MK")])
+    assert (labels, strs) == ref["empty_string_batch"][:2] and torch.equal(toks, ref["empty_string_batch"][2])
