@@ -33,6 +33,20 @@ MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_M
 HBM_PEAK_GBS = 8000.0
 
 
+def argmax_report(logits, ref_logits):
+    """Token-argmax agreement with the CPU path.  Random-init weights give near-tied logits, so the raw agreement
+    counts coin flips; `decided` restricts it to positions whose top-2 margin in the reference exceeds twice the
+    largest logit difference — there the argmax must be identical (north star: token argmax bit-exact)."""
+    err = (logits - ref_logits).abs().max().item()
+    top2 = ref_logits.topk(2, dim=-1).values
+    decided = (top2[..., 0] - top2[..., 1]) > 2 * err
+    same = logits.argmax(-1) == ref_logits.argmax(-1)
+    return {"logits_argmax_agreement": same.float().mean().item(),
+            "logits_max_abs_diff": err,
+            "decided_positions": int(decided.sum().item()),
+            "argmax_agreement_where_decided": same[decided].float().mean().item() if bool(decided.any()) else None}
+
+
 def timed_steps(step, steps, warmup, sync_all, dist, dev):
     """The contract's timed region: `warmup` untimed steps, then exactly `steps` steps bracketed by
     synchronise + barrier on both sides; returns the MAX elapsed seconds over ranks."""
@@ -226,7 +240,10 @@ def main():
             r_gpu, r_ref = got["representations"][L].cpu(), ref["representations"][L]
             max_abs = (r_gpu - r_ref).abs().max().item()
             rel = max_abs / r_ref.abs().max().item()
-            agree = (got["logits"].cpu().argmax(-1) == ref["logits"].argmax(-1)).float().mean().item()
+            try:
+                amax = argmax_report(got["logits"].float().cpu(), ref["logits"].float())
+            except Exception as e:  # never lose the JSON line over a report detail
+                amax = {"logits_argmax_agreement": None, "error": str(e)}
             result["cpu_baseline"] = {
                 "value": round(cpu_value, 1),
                 "unit": "residues/s",
@@ -238,7 +255,7 @@ def main():
             result["parity"] = {
                 "max_abs_repr_diff_vs_cpu": max_abs,
                 "rel_repr_diff_vs_cpu": rel,
-                "logits_argmax_agreement": agree,
+                **amax,
                 "sample_sequences": int(sample.shape[0]),
             }
         print(json.dumps(result), flush=True)

@@ -32,3 +32,21 @@ def test_single_process_protocol():
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert r["n_gpus"] == 1 and 4.5 <= r["ms_per_step"] < 40
+
+
+def test_argmax_report():
+    import importlib.util
+
+    import torch
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ref = torch.tensor([[[5.0, 1.0, 0.0], [2.0, 2.0005, 0.0], [0.0, 3.0, 2.9]]])
+    got = ref.clone()
+    got[0, 1] = torch.tensor([2.001, 2.0, 0.0])   # near-tie flips: not a decided position
+    got[0, 0, 0] += 0.002
+    r = bench.argmax_report(got, ref)
+    assert abs(r["logits_argmax_agreement"] - 2 / 3) < 1e-6
+    assert r["decided_positions"] == 2 and r["argmax_agreement_where_decided"] == 1.0
+    assert abs(r["logits_max_abs_diff"] - 0.002) < 1e-6
