@@ -270,6 +270,24 @@ def main():
         "esm2_default": {"attrs": {a: getattr(esm.ESM2(num_layers=1), a) for a in ("embed_dim", "attention_heads")}},
     }
 
+    # ---- the reference-side binding stub on the REAL reference class (examples/reference_binding/_esmk.py) ------
+    import ctypes
+
+    spec = importlib.util.spec_from_file_location("ref_esmk_stub", os.path.join(ROOT, "examples", "reference_binding", "_esmk.py"))
+    stub = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(stub)
+    libpath = os.path.join(ROOT, "esm_amd", "lib", "libesmk.so")
+    if os.path.exists(libpath):
+        L_ = stub.lib(libpath)
+        m = esm.ESM2(6, 320, 20)
+        cfg = stub.config_for(m)  # reads the attributes the reference's ESM2.__init__ sets
+        h, n = ctypes.c_void_p(), ctypes.c_size_t()
+        rc = L_.esmk_create(ctypes.byref(cfg), ctypes.byref(h))
+        L_.esmk_packed_bytes(h, ctypes.byref(n))
+        L_.esmk_destroy(h)
+        res["stub"] = dict(rc=rc, packed_bytes=n.value, cfg=[getattr(cfg, f[0]) for f in stub.Config._fields_],
+                           state_keys=[k for k in m.state_dict()])
+
     with open(out_path, "wb") as f:
         pickle.dump(res, f)
 

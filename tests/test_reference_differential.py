@@ -284,3 +284,26 @@ def test_alphabet_object_and_dataset_edge_cases(probe, tmp_path):
     a = esm.Alphabet.from_architecture("ESM-1b")
     labels, strs, toks = a.get_batch_converter()([("e", ""), ("f", "MK")])
     assert (labels, strs) == ref["empty_string_batch"][:2] and torch.equal(toks, ref["empty_string_batch"][2])
+
+
+def test_binding_stub_reads_the_real_reference_class(probe):
+    """examples/reference_binding/_esmk.py configured from an instance of the REFERENCE's ESM2 (attribute names of
+    esm2.py:24-38): esmk_create accepts it and plans the same packed image as for this repo's class."""
+    import ctypes
+
+    import esm
+    from esm_amd import _native
+
+    if "stub" not in probe:
+        pytest.skip("libesmk.so not built")
+    assert probe["stub"]["rc"] == 0
+    m = esm.ESM2(6, 320, 20)
+    cfg = _native.EsmkConfig(6, 320, 20, 1280, m.alphabet_size, m.padding_idx, m.mask_idx, m.cls_idx, m.eos_idx, 1, 1, 1,
+                             _native.dtype_code(torch.float16), 0, 0, 0)
+    assert probe["stub"]["cfg"] == [getattr(cfg, f[0]) for f in _native.EsmkConfig._fields_]
+    h, n = ctypes.c_void_p(), ctypes.c_size_t()
+    _native.check(_native.lib.esmk_create(ctypes.byref(cfg), ctypes.byref(h)))
+    _native.check(_native.lib.esmk_packed_bytes(h, ctypes.byref(n)))
+    _native.lib.esmk_destroy(h)
+    assert n.value == probe["stub"]["packed_bytes"]
+    assert probe["stub"]["state_keys"] == list(m.state_dict())  # every key esmk_pack_weight will be handed
