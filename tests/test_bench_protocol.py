@@ -21,7 +21,7 @@ def test_two_rank_protocol(tmp_path):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 4 and r["warmup"] == 1 and r["scaling"] == "weak"
     # rank 1's steps take 10 ms: the MAX over ranks is reported, not rank 0's own 5 ms
-    assert 9.5 <= r["ms_per_step"] < 60, r
+    assert 9.5 <= r["ms_per_step"] < 1000, r  # lower bound is the point; the upper one only guards nonsense
     assert abs(r["value"] - 2 * 64 * 1022 * 4 / (r["ms_per_step"] * 4e-3)) / r["value"] < 1e-3
 
 
@@ -31,7 +31,7 @@ def test_single_process_protocol():
                          timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
-    assert r["n_gpus"] == 1 and 4.5 <= r["ms_per_step"] < 40
+    assert r["n_gpus"] == 1 and 4.5 <= r["ms_per_step"] < 1000
 
 
 def test_argmax_report():
