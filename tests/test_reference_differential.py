@@ -307,3 +307,55 @@ def test_binding_stub_reads_the_real_reference_class(probe):
     _native.lib.esmk_destroy(h)
     assert n.value == probe["stub"]["packed_bytes"]
     assert probe["stub"]["state_keys"] == list(m.state_dict())  # every key esmk_pack_weight will be handed
+
+
+def test_extraction_driver_writes_the_files_the_reference_script_writes(tmp_path):
+    """esm_amd.extract.extract (the sharded driver; here one rank on CPU with the oracle as its embed_fn — test
+    infrastructure, the product's embed_fn is the engine) against the reference's scripts/extract.py run on the same
+    checkpoint and FASTA: the same set of <label>.pt files, the same keys, dtypes and shapes, truncation at
+    --truncation_seq_length, values to oracle precision."""
+    import pathlib
+
+    import esm
+    from esm_amd.extract import extract
+    from esm_amd.synth import synth_esm2_state_dict, write_esm2_checkpoint
+    from oracle.esm2_oracle import esm2_forward
+
+    L, E, H = 3, 128, 2
+    ckpt = write_esm2_checkpoint(str(tmp_path), "esm2_t3_tiny_UR50D", L, E, H, seed=17)
+    g = torch.Generator().manual_seed(8)
+    aas = "LAGVSERTIDPKQNFYMHWC"
+    seqs = {f"sp|P{i:05d}|NAME_{i} desc": "".join(aas[j] for j in torch.randint(0, 20, (n,), generator=g).tolist())
+            for i, n in enumerate([12, 55, 31, 70, 8])}
+    fasta = tmp_path / "in.fasta"
+    fasta.write_text("".join(f">{k}\n{v}\n" for k, v in seqs.items()))
+    common = ["--repr_layers", "-1", "1", "--include", "mean", "per_tok", "bos", "contacts", "--truncation_seq_length", "40",
+              "--toks_per_batch", "150"]
+    r = subprocess.run([sys.executable, os.path.join(REFERENCE, "scripts", "extract.py"), ckpt, str(fasta),
+                        str(tmp_path / "ref"), "--nogpu"] + common, capture_output=True, text=True, cwd=str(tmp_path),
+                       env=dict(os.environ, PYTHONPATH=REFERENCE, TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD="1"), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+    sd = synth_esm2_state_dict(L, E, H, seed=17)
+    alphabet = esm.Alphabet.from_architecture("ESM-1b")
+    ds = esm.FastaBatchedDataset.from_file(fasta)
+
+    def embed_fn(toks, layers, return_contacts):
+        return esm2_forward(sd, toks, L, H, repr_layers=layers, return_contacts=return_contacts)
+
+    extract(ds, alphabet, embed_fn, L, E, [-1, 1], ["mean", "per_tok", "bos", "contacts"],
+            output_dir=pathlib.Path(tmp_path / "ours"), toks_per_batch=150, truncation_seq_length=40, device=None,
+            gather_mean=False, log=lambda s: None)
+    ref_files = sorted(p.relative_to(tmp_path / "ref") for p in (tmp_path / "ref").rglob("*.pt"))
+    our_files = sorted(p.relative_to(tmp_path / "ours") for p in (tmp_path / "ours").rglob("*.pt"))
+    assert ref_files == our_files and len(ref_files) == 5
+    for rel in ref_files:
+        a = torch.load(tmp_path / "ref" / rel, weights_only=False)
+        b = torch.load(tmp_path / "ours" / rel, weights_only=False)
+        assert a["label"] == b["label"] and sorted(a) == sorted(b)
+        for key in ("representations", "mean_representations", "bos_representations"):
+            assert sorted(a[key]) == sorted(b[key]) == [1, L]
+            for l in a[key]:
+                assert a[key][l].shape == b[key][l].shape and a[key][l].dtype == b[key][l].dtype, (rel, key, l)
+                assert (a[key][l] - b[key][l]).abs().max().item() < 5e-5
+        assert a["contacts"].shape == b["contacts"].shape and (a["contacts"] - b["contacts"]).abs().max().item() < 5e-5
