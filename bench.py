@@ -1,20 +1,31 @@
 #!/usr/bin/env python
-"""Benchmark of the hot path: ESM-2 650M bulk embedding extraction on synthetic L=1022 batches.
+"""Benchmark of the hot path on MI355X.  Default: ESM-2 650M bulk embedding extraction, synthetic L=1022 batches.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload NAME]
 
-One "step" = one forward pass (``model(tokens, repr_layers=[33])``, the call scripts/extract.py:95
-makes) over one batch of B sequences of 1022 residues per GPU, inputs resident in HBM, outputs left
-on the device.  Sequences are independent, so ranks shard the batch with no data-path collective
-(weak scaling); the only collectives are the timing barrier and the MAX over ranks.
+``--gpus N`` from a plain shell re-executes this script as N ranks (one per GPU) under torch.distributed.run
+(esm_amd/launch.py); started by a launcher already (RANK / WORLD_SIZE set) it joins it.  Ranks create the process
+group with backend "nccl" (= RCCL over xGMI), check world size / backend and run one all-reduce before anything is
+timed.  Sequences are independent, so ranks shard the batch with no data-path collective (weak scaling); the only
+collectives are the timing barrier and the MAX over ranks.
 
-Prints ONE JSON line (rank 0): metric residues/sec (whole job), plus
-  roofline     : dominant kernel class vs the fp16/bf16 MFMA roof (2.5 PFLOP/s dense), measured with
-                 HIP events on the launch stream in extra profiled steps after the timed region;
-  cpu_baseline : the oracle (CPU restatement of the reference, oracle/esm2_oracle.py) timed on the
-                 host cores on a bounded sample of the same workload (rank 0, N=1 only), and the
-                 max-abs / relative difference of representations[33] against it.
+Workloads (one "step" each; the default is BASELINE.json's headline configuration, the others make the remaining
+BASELINE configs driver-measurable):
+  esm2_650m         model(tokens [B,1024], repr_layers=[33])            — the call scripts/extract.py:95 makes
+  esm2_3b_contacts  model.predict_contacts(tokens [B,1024]) at 3B dims   — config 3
+  msa1b             model(tokens [1,128,513], repr_layers=[12])          — config 5 (MSA Transformer axial path)
+  extract_650m      the extraction driver end to end: FASTA strings -> tokens -> forward -> device->host ->
+                    per-sequence .pt files written (--include mean per_tok), SURVEY §8 f-3
+
+Prints ONE JSON line (rank 0): metric residues/sec (whole job) plus
+  roofline            dominant kernel class vs the fp16/bf16 MFMA roof (2.5 PFLOP/s dense), HIP events on the launch
+                      stream in extra profiled steps after the timed region; `traffic` = HBM bytes per launch from the
+                      committed rocprofv3 PMC pass — only when that pass was taken on THIS build of the library
+                      (source hash in esmk_version()), else null;
+  roofline_attention  the attention kernel against the same roof;  roofline_hbm: LayerNorm against 8 TB/s HBM;
+  e2e_with_d2h        SURVEY §8 d figure (ii): forward + device->host copy of representations[33], overlapped;
+  cpu_baseline        the oracle (CPU restatement of the reference, oracle/esm2_oracle.py) timed on the host cores
+                      at B=1 (1 warm-up + 3 timed, median) and B=4, and the parity of the GPU outputs against it.
 """
 import argparse
 import json
@@ -27,10 +38,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MODEL = "esm2_t33_650M_UR50D"
-FLOP_PER_RESIDUE = 1.4769e9  # SURVEY.md §8 d: 1.509 TFLOP per 1024-token sequence / 1022 residues
 MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
-HBM_PEAK_GBS = 8000.0
+HBM_PEAK_GBS = 8000.0        # spec; 6.29 TB/s is the measured copy ceiling
+HBM_ACHIEVABLE_GBS = 6300.0
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r2_pmc_summary.json")
 
 
 def argmax_report(logits, ref_logits):
@@ -41,9 +52,12 @@ def argmax_report(logits, ref_logits):
     top2 = ref_logits.topk(2, dim=-1).values
     decided = (top2[..., 0] - top2[..., 1]) > 2 * err
     same = logits.argmax(-1) == ref_logits.argmax(-1)
+    n = logits[..., 0].numel()
     return {"logits_argmax_agreement": same.float().mean().item(),
             "logits_max_abs_diff": err,
+            "positions": n,
             "decided_positions": int(decided.sum().item()),
+            "undecided_fraction": round(1.0 - decided.sum().item() / n, 5),
             "argmax_agreement_where_decided": same[decided].float().mean().item() if bool(decided.any()) else None}
 
 
@@ -65,21 +79,19 @@ def timed_steps(step, steps, warmup, sync_all, dist, dev):
     return elapsed
 
 
-def protocol_test(args):
-    """Same rank / world handling, barriers, MAX-over-ranks and single JSON line as the real run, on CPU with the
-    gloo backend and a stub step that takes 5 ms x (rank + 1): there is no GPU in the build container and the 8-GPU
-    run belongs to the driver, so this is what keeps the N > 1 path honest."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+def finish(dist):
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+def protocol_test(args):
+    """Same launch (self-spawn or external launcher), rank / world handling, barriers, MAX-over-ranks and single JSON
+    line as the real run, on CPU with the gloo backend and a stub step that takes 5 ms x (rank + 1): there is no GPU
+    in the build container and the 8-GPU run belongs to the driver, so this is what keeps the N > 1 path honest."""
+    from esm_amd.launch import init_ranks
+
+    dist, rank, world, _ = init_ranks(args.gpus, "gloo")
     dev = torch.device("cpu")
 
     def sync_all():
@@ -91,56 +103,112 @@ def protocol_test(args):
         print(json.dumps({"metric": "protocol-test (not a measurement)", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
                           "value": round(world * args.batch * args.seq_len * args.steps / elapsed, 1),
-                          "scaling": "weak"}), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+                          "scaling": "weak", "backend": dist.get_backend() if dist is not None else None,
+                          "launched_by": os.environ.get("ESM_AMD_BENCH_LAUNCH", "external-or-single")}), flush=True)
+    finish(dist)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU per step")
-    ap.add_argument("--seq-len", type=int, default=1022)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2, help="sequences in the CPU baseline sample")
-    ap.add_argument("--protocol-test", action="store_true",
-                    help="CPU/gloo dry run of the launch + timing protocol with a stub step (tests/test_bench_protocol.py); "
-                         "never a measurement")
-    args = ap.parse_args()
-    if args.protocol_test:
-        return protocol_test(args)
+# ---------------------------------------------------------------------------------------------------------------
+def operand_name():
+    return "bf16" if os.environ.get("ESM_AMD_OPERAND", "").lower() in ("bf16", "bfloat16") else "f16"
 
+
+def library_build():
+    from esm_amd import _native
+    from esm_amd.build import library_hash
+
+    return {"version": _native.lib.esmk_version().decode(), "src_hash": library_hash(_native.LIB_PATH)}
+
+
+def class_table(prof, prof_steps):
+    return {
+        e["name"]: {
+            "ms_per_step": round(e["ms"] / prof_steps, 4),
+            "launches_per_step": e["launches"] // prof_steps,
+            "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 1) if e["flops"] and e["ms"] > 0 else None,
+            "gbs": round(e["bytes"] / (e["ms"] * 1e-3) / 1e9, 1) if e["ms"] > 0 else None,
+        }
+        for e in prof
+    }
+
+
+def pmc_traffic(kernel_class, src_hash):
+    """HBM bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes (tools/profile_bench.sh ->
+    profiles/r2_pmc_summary.json; FETCH_SIZE doubled as the microarch guide prescribes for gfx950).  The summary
+    records the source hash of the library it profiled: a different build -> null (never a stale number)."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            s = json.load(f)
+        if s.get("library_src_hash") != src_hash:
+            return None, f"PMC summary is from build {s.get('library_src_hash')}, this is {src_hash}"
+        return s["kernels"][kernel_class]["hbm_bytes_corrected"], s.get("git_sha")
+    except Exception as e:  # missing file / class
+        return None, str(e)
+
+
+def mfma_roofline(prof, name=None):
+    cand = [e for e in prof if e["flops"] > 0 and e["launches"] > 0]
+    dom = max(cand, key=lambda e: e["ms"]) if name is None else next(e for e in cand if e["name"] == name)
+    ms = dom["ms"] / dom["launches"]
+    achieved = dom["flops"] / dom["launches"] / (ms * 1e-3) / 1e12
+    return dom, {
+        "kernel": dom["name"], "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "avg_launch_ms": round(ms, 4), "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
+    }
+
+
+def hbm_roofline(prof, name="layernorm"):
+    e = next((e for e in prof if e["name"] == name and e["launches"] > 0), None)
+    if e is None:
+        return None
+    ms = e["ms"] / e["launches"]
+    gbs = e["bytes"] / e["launches"] / (ms * 1e-3) / 1e9
+    return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(gbs / HBM_ACHIEVABLE_GBS, 4),
+            "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": e["bytes"] / e["launches"], "traffic": None}
+
+
+def profile_steps(model, step, prof_steps=2):
+    model.profile_begin()
+    for _ in range(prof_steps):
+        step()
+    return model.profile_end(), prof_steps
+
+
+def base_result(args, world, metric, value, elapsed, workload, extra_cfg):
+    return {
+        "metric": metric, "value": round(value, 1), "unit": "residues/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": operand_name(), "data": "synthetic",
+        "config": {"workload": workload, "sharding": f"dp{world} (no data-path collective)", **extra_cfg},
+        "host_cores": os.cpu_count(),
+    }
+
+
+def cpu_threads():
+    # MKL on all 256 hardware threads of the GPU host is 30x SLOWER than on 32 (measured: 11 vs 354 residues/s,
+    # tools/cpu_threads_probe.py); ESM_AMD_CPU_THREADS overrides
+    n = min(os.cpu_count() or 1, int(os.environ.get("ESM_AMD_CPU_THREADS", "32")))
+    torch.set_num_threads(n)
+    return n
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def run_esm2_650m(args, dist, rank, world, dev):
     import esm
     from esm_amd.synth import ESM2_DIMS, synth_esm2_state_dict, synth_tokens
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-
+    MODEL = "esm2_t33_650M_UR50D"
+    FLOP_PER_RESIDUE = 1.4769e9  # SURVEY.md §8 d: 1.509 TFLOP per 1024-token sequence / 1022 residues
     L, E, H = ESM2_DIMS[MODEL]
     sd = synth_esm2_state_dict(L, E, H, seed=0)          # identical replica on every rank
     model = esm.ESM2(L, E, H).eval()
     model.load_state_dict(sd)
     model = model.to(dev)
-    toks = synth_tokens(args.batch, args.seq_len, seed=1 + rank).to(dev)  # each rank its own shard
-    residues_per_step = args.batch * args.seq_len
+    batch = args.batch or 64
+    toks = synth_tokens(batch, args.seq_len, seed=1 + rank).to(dev)  # each rank its own shard
+    residues_per_step = batch * args.seq_len
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -148,120 +216,339 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    step = lambda: model(toks, repr_layers=[L])
     with torch.no_grad():
-        elapsed = timed_steps(lambda: model(toks, repr_layers=[L]), args.steps, args.warmup, sync_all, dist, dev)
+        elapsed = timed_steps(step, args.steps, args.warmup, sync_all, dist, dev)
+        prof, prof_steps = profile_steps(model, step)  # separate steps: the timed region is unperturbed
 
-        # per-kernel-class timing with HIP events (separate steps so the timed region is unperturbed)
-        prof_steps = 2
-        model.profile_begin()
-        for _ in range(prof_steps):
-            model(toks, repr_layers=[L])
-        prof = model.profile_end()
+        # figure (ii): every step's representations[33] also goes to pinned host memory on a side stream while the
+        # next forward runs (what the extraction driver does, scripts/extract.py:97-100)
+        d2h_steps = max(2, min(args.steps, 10))
+        copy_stream = torch.cuda.Stream(dev)
+        host = [torch.empty((batch, args.seq_len + 2, E), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        done = [torch.cuda.Event() for _ in range(2)]
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(d2h_steps):
+            out = model(toks, repr_layers=[L])["representations"][L]
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))
+            if i >= 2:
+                done[i % 2].synchronize()  # the host buffer is free again
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ready)
+                host[i % 2].copy_(out, non_blocking=True)
+                out.record_stream(copy_stream)
+                done[i % 2].record(copy_stream)
+        copy_stream.synchronize()
+        sync_all()
+        d2h_elapsed = time.perf_counter() - t0
 
     value = world * residues_per_step * args.steps / elapsed
-    ms_per_step = 1e3 * elapsed / args.steps
+    if rank != 0:
+        return None
+    result = base_result(
+        args, world, "residues/sec (whole node) ESM-2 650M L=1022 bulk extract", value, elapsed,
+        f"{MODEL} forward (repr_layers=[33] + logits), synthetic tokens [B,{args.seq_len + 2}], random-init weights "
+        "of the 650M architecture", {"batch_per_gpu": batch, "seq_len": args.seq_len})
+    build = library_build()
+    dom, roof = mfma_roofline(prof)
+    roof["traffic"], roof["traffic_source"] = pmc_traffic(dom["name"], build["src_hash"])
+    result["e2e_mfma_frac_per_gpu"] = round(value / world * FLOP_PER_RESIDUE / (MFMA_PEAK_TFLOPS * 1e12), 4)
+    result["roofline"] = roof
+    _, ra = mfma_roofline(prof, "attention")
+    ra["traffic"], _ = pmc_traffic("attention", build["src_hash"])
+    result["roofline_attention"] = ra
+    rh = hbm_roofline(prof)
+    if rh is not None:
+        rh["traffic"], _ = pmc_traffic("layernorm", build["src_hash"])
+    result["roofline_hbm"] = rh
+    result["kernel_classes"] = class_table(prof, prof_steps)
+    result["profiled_ms_per_step"] = round(sum(e["ms"] for e in prof) / prof_steps, 3)
+    result["e2e_with_d2h"] = {
+        "value": round(residues_per_step * d2h_steps / d2h_elapsed, 1), "unit": "residues/s (this rank)",
+        "steps": d2h_steps, "what": "forward + device->host copy of representations[33] (fp32, "
+                                    f"{batch * (args.seq_len + 2) * E * 4 / 1e6:.0f} MB per step) into pinned memory on a "
+                                    "side stream, overlapped with the next forward"}
+    result["library"] = build
 
-    result = None
-    if rank == 0:
-        dom = max(prof, key=lambda e: e["ms"])
-        dom_ms = dom["ms"] / dom["launches"]
-        achieved = dom["flops"] / dom["launches"] / (dom_ms * 1e-3) / 1e12
-        total_ms = sum(e["ms"] for e in prof) / prof_steps
-        classes = {
-            e["name"]: {
-                "ms_per_step": round(e["ms"] / prof_steps, 4),
-                "launches_per_step": e["launches"] // prof_steps,
-                "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 1) if e["flops"] else None,
-                "gbs": round(e["bytes"] / (e["ms"] * 1e-3) / 1e9, 1),
-            }
-            for e in prof
-        }
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-        # (tools/profile_bench.sh -> profiles/r1_pmc_summary.json; FETCH_SIZE doubled as the microarch
-        # guide prescribes for gfx950).  null when no profile of this kernel class is committed.
-        traffic = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.esm2_oracle import esm2_forward
+
+        ncores = cpu_threads()
+        # SURVEY §8 d: B = 1 and B = 4, 1 warm-up + 3 timed forwards, median.  B = 4 costs ~12 s per forward on the
+        # GPU host, so it is timed once after the warm caches of B = 1 (the sample stays inside ~30 s of CPU work).
+        s1, s4 = toks[:1].cpu(), toks[:4].cpu()
+        t1 = []
+        for _ in range(4):
+            c0 = time.perf_counter()
+            esm2_forward(sd, s1, L, H, repr_layers=[L])
+            t1.append(time.perf_counter() - c0)
+        med1 = sorted(t1[1:])[1]
+        c0 = time.perf_counter()
+        ref = esm2_forward(sd, s4, L, H, repr_layers=[L])
+        t4 = time.perf_counter() - c0
+        with torch.no_grad():
+            got = model(toks[:4], repr_layers=[L])
+        r_gpu, r_ref = got["representations"][L].cpu().double(), ref["representations"][L].double()
+        max_abs = (r_gpu - r_ref).abs().max().item()
         try:
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as f:
-                traffic = json.load(f)["kernels"][dom["name"]]["hbm_bytes_corrected"]
-        except Exception:
-            traffic = None
-        result = {
-            "metric": "residues/sec (whole node) ESM-2 650M L=1022 bulk extract",
-            "value": round(value, 1),
-            "unit": "residues/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16" if os.environ.get("ESM_AMD_OPERAND", "").lower() in ("bf16", "bfloat16") else "f16",
-            "data": "synthetic",
-            "config": {
-                "workload": f"{MODEL} forward (repr_layers=[33] + logits), synthetic tokens [B,{args.seq_len + 2}], "
-                            "random-init weights of the 650M architecture",
-                "batch_per_gpu": args.batch, "seq_len": args.seq_len, "sharding": f"dp{world} (no data-path collective)",
-            },
-            "e2e_mfma_frac_per_gpu": round(value / world * FLOP_PER_RESIDUE / (MFMA_PEAK_TFLOPS * 1e12), 4),
-            "roofline": {
-                "kernel": dom["name"],
-                "bound": "mfma",
-                "achieved": round(achieved, 1),
-                "peak": MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                "traffic": traffic,
-                "avg_launch_ms": round(dom_ms, 4),
-                "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
-            },
-            "kernel_classes": classes,
-            "profiled_ms_per_step": round(total_ms, 3),
+            amax = argmax_report(got["logits"].float().cpu(), ref["logits"].float())
+        except Exception as e:  # never lose the JSON line over a report detail
+            amax = {"logits_argmax_agreement": None, "error": str(e)}
+        result["cpu_baseline"] = {
+            "value": round(4 * args.seq_len / t4, 1), "unit": "residues/s", "cores": torch.get_num_threads(),
+            "host_cores": os.cpu_count(), "kind": "port",
+            "sample": f"fp32 oracle on {ncores} threads: B=4 sequences of the timed batch (L={args.seq_len}), 1 forward "
+                      f"after the B=1 runs; B=1: 1 warm-up + 3 timed, median",
+            "b1_residues_per_s": round(args.seq_len / med1, 1), "b1_seconds": [round(t, 3) for t in t1],
+            "b4_seconds": round(t4, 3),
         }
+        result["parity"] = {
+            "max_abs_repr_diff_vs_cpu": max_abs,
+            "rel_repr_diff_vs_cpu": max_abs / r_ref.abs().max().item(),
+            "rel_l2_repr_diff_vs_cpu": ((r_gpu - r_ref).norm() / r_ref.norm()).item(),
+            **amax, "sample_sequences": 4,
+        }
+    return result
 
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle.esm2_oracle import esm2_forward
 
-            # MKL on all 256 hardware threads of the GPU host is 30x SLOWER than on 32 (measured:
-            # 11 vs 354 residues/s, tools/cpu_threads_probe.py); use the best setting found
-            ncores = min(os.cpu_count() or 1, int(os.environ.get("ESM_AMD_CPU_THREADS", "32")))
-            torch.set_num_threads(ncores)
-            sample = toks[: args.cpu_sample].cpu()
-            t_cpu = []
-            ref = None
-            for i in range(3):
-                c0 = time.perf_counter()
-                ref = esm2_forward(sd, sample, L, H, repr_layers=[L])
-                t_cpu.append(time.perf_counter() - c0)
-            t_med = sorted(t_cpu[1:])[0] if len(t_cpu) > 1 else t_cpu[0]
-            cpu_value = sample.shape[0] * args.seq_len / t_med
-            with torch.no_grad():
-                got = model(toks[: args.cpu_sample], repr_layers=[L])
-            r_gpu, r_ref = got["representations"][L].cpu(), ref["representations"][L]
-            max_abs = (r_gpu - r_ref).abs().max().item()
-            rel = max_abs / r_ref.abs().max().item()
-            try:
-                amax = argmax_report(got["logits"].float().cpu(), ref["logits"].float())
-            except Exception as e:  # never lose the JSON line over a report detail
-                amax = {"logits_argmax_agreement": None, "error": str(e)}
-            result["cpu_baseline"] = {
-                "value": round(cpu_value, 1),
-                "unit": "residues/s",
-                "cores": torch.get_num_threads(),
-                "kind": "port",
-                "sample": f"{sample.shape[0]} sequences of the timed batch (L={args.seq_len}), fp32 oracle, "
-                          f"best of {len(t_cpu) - 1} after 1 warm-up",
-            }
-            result["parity"] = {
-                "max_abs_repr_diff_vs_cpu": max_abs,
-                "rel_repr_diff_vs_cpu": rel,
-                **amax,
-                "sample_sequences": int(sample.shape[0]),
-            }
+def run_esm2_3b_contacts(args, dist, rank, world, dev):
+    import esm
+    from esm_amd.synth import ESM2_DIMS, synth_esm2_state_dict, synth_tokens
+
+    MODEL = "esm2_t36_3B_UR50D"
+    L, E, H = ESM2_DIMS[MODEL]
+    T = args.seq_len + 2
+    flop_per_seq = L * (24.0 * E * E + 4.0 * T * E) * T  # the transformer stack (SURVEY §8 a); the contact pass
+    sd = synth_esm2_state_dict(L, E, H, seed=2)          # recomputes QK^T once more (+2TE per token-layer)
+    model = esm.ESM2(L, E, H).eval()
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    batch = args.batch or 16
+    toks = synth_tokens(batch, args.seq_len, seed=1 + rank).to(dev)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    step = lambda: model.predict_contacts(toks)
+    with torch.no_grad():
+        elapsed = timed_steps(step, args.steps, args.warmup, sync_all, dist, dev)
+        prof, prof_steps = profile_steps(model, step)
+    value = world * batch * args.seq_len * args.steps / elapsed
+    if rank != 0:
+        return None
+    result = base_result(
+        args, world, "residues/sec ESM-2 3B L=1022 contact prediction (predict_contacts)", value, elapsed,
+        f"{MODEL} predict_contacts(tokens [B,{T}]): 36-layer forward + contact head without the [B,L,H,T,T] tensor, "
+        "random-init weights of the 3B architecture", {"batch_per_gpu": batch, "seq_len": args.seq_len})
+    result["e2e_mfma_frac_per_gpu"] = round(value / world / args.seq_len * flop_per_seq / (MFMA_PEAK_TFLOPS * 1e12), 4)
+    _, result["roofline"] = mfma_roofline(prof)
+    result["roofline_hbm"] = hbm_roofline(prof)
+    result["kernel_classes"] = class_table(prof, prof_steps)
+    result["library"] = library_build()
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.esm2_oracle import esm2_forward
+
+        ncores = cpu_threads()
+        small = synth_tokens(1, 256, seed=5)  # bounded sample: the oracle materialises [1440,T,T] four times
+        c0 = time.perf_counter()
+        ref = esm2_forward(sd, small, L, H, repr_layers=[L], return_contacts=True)
+        t_cpu = time.perf_counter() - c0
+        with torch.no_grad():
+            got = model.predict_contacts(small.to(dev)).cpu()
+        lg = lambda t: torch.logit(t.double().clamp(1e-12, 1 - 1e-12))
+        z, zr = lg(got), lg(ref["contacts"])
+        result["cpu_baseline"] = {"value": round(256 / t_cpu, 1), "unit": "residues/s", "cores": ncores,
+                                  "host_cores": os.cpu_count(), "kind": "port",
+                                  "sample": "one sequence of 256 residues through the fp32 oracle with contacts, 1 run"}
+        result["parity"] = {"contacts_max_abs_prob_diff": (got - ref["contacts"]).abs().max().item(),
+                            "contacts_max_abs_logit_diff": (z - zr).abs().max().item(),
+                            "contacts_logit_diff_rel_to_range": ((z - zr).abs().max() / zr.abs().max()).item()}
+    return result
+
+
+def run_msa1b(args, dist, rank, world, dev):
+    import esm
+    from esm_amd.synth import MSA_DIMS, synth_msa_state_dict, synth_msa_tokens
+
+    L, E, H, F = MSA_DIMS["esm_msa1b_t12_100M_UR50S"]
+    R, C = 128, 513
+    ns = argparse.Namespace(layers=L, embed_dim=E, ffn_embed_dim=F, attention_heads=H, dropout=0.1, attention_dropout=0.1,
+                            activation_dropout=0.1, max_positions=1024, embed_positions_msa=True,
+                            embed_positions_msa_dim=E, max_tokens=2 ** 14, max_tokens_per_msa=2 ** 14)
+    sd = synth_msa_state_dict(L, E, H, F, seed=0)
+    model = esm.MSATransformer(ns, esm.Alphabet.from_architecture("msa_transformer")).eval()
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    batch = args.batch or 1
+    toks = synth_msa_tokens(batch, R, C, seed=1 + rank).to(dev)
+    ntok = batch * R * C
+    flop = ntok * L * (32.0 * E * E + 4.0 * E * (C + R))  # SURVEY §8 a: 16.5 TFLOP per 128 x 513 MSA
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    step = lambda: model(toks, repr_layers=[L])
+    with torch.no_grad():
+        elapsed = timed_steps(step, args.steps, args.warmup, sync_all, dist, dev)
+        prof, prof_steps = profile_steps(model, step)
+    residues = batch * R * (C - 1)
+    value = world * residues * args.steps / elapsed
+    if rank != 0:
+        return None
+    result = base_result(
+        args, world, "MSA residues/sec esm_msa1b_t12_100M 128-seq MSA L=512", value, elapsed,
+        f"esm_msa1b_t12_100M dims (12 x 768, 12 heads): model(tokens [{batch},{R},{C}], repr_layers=[12]) — tied row "
+        "attention + column attention + FFN, random-init weights", {"msas_per_gpu": batch, "rows": R, "cols": C})
+    result["e2e_mfma_frac_per_gpu"] = round(flop * args.steps / elapsed / (MFMA_PEAK_TFLOPS * 1e12), 4)
+    result["tflops_algorithmic"] = round(flop * args.steps / elapsed / 1e12, 1)
+    _, result["roofline"] = mfma_roofline(prof)
+    result["roofline_hbm"] = hbm_roofline(prof)
+    result["kernel_classes"] = class_table(prof, prof_steps)
+    result["library"] = library_build()
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.msa_oracle import msa_forward
+
+        ncores = cpu_threads()
+        small = toks[:1, :32].cpu()  # bounded sample: a 32-row slice of the same MSA (depth changes the tied scale)
+        c0 = time.perf_counter()
+        ref = msa_forward(sd, small, L, H, repr_layers=[L])
+        t_cpu = time.perf_counter() - c0
+        with torch.no_grad():
+            got = model(small.to(dev), repr_layers=[L])
+        r_gpu, r_ref = got["representations"][L].cpu().double(), ref["representations"][L].double()
+        result["cpu_baseline"] = {"value": round(32 * (C - 1) / t_cpu, 1), "unit": "residues/s", "cores": ncores,
+                                  "host_cores": os.cpu_count(), "kind": "port",
+                                  "sample": "the first 32 rows of the MSA (32 x 513) through the fp32 oracle, 1 run"}
+        result["parity"] = {"rel_repr_diff_vs_cpu": ((r_gpu - r_ref).abs().max() / r_ref.abs().max()).item(),
+                            "rel_l2_repr_diff_vs_cpu": ((r_gpu - r_ref).norm() / r_ref.norm()).item(),
+                            **argmax_report(got["logits"].float().cpu(), ref["logits"].float())}
+    return result
+
+
+def run_extract_650m(args, dist, rank, world, dev):
+    """The extraction driver end to end with result files written.  One step = one 64-sequence
+    batch through tokenise -> forward -> device->host -> per-sequence torch.save (reference file format,
+    scripts/extract.py:104-131).  --out-dir chooses the file system (default: a tmpfs directory under /dev/shm)."""
+    import pathlib
+    import shutil
+    import tempfile
+
+    import esm
+    from esm_amd.extract import default_writer_threads, extract, make_embed_fn
+    from esm_amd.synth import ESM2_DIMS, synth_esm2_state_dict
+
+    L, E, H = ESM2_DIMS["esm2_t33_650M_UR50D"]
+    model = esm.ESM2(L, E, H).eval()
+    model.load_state_dict(synth_esm2_state_dict(L, E, H, seed=0))
+    model = model.to(dev)
+    batch = args.batch or 64
+    g = torch.Generator().manual_seed(1 + rank)
+    aas = "LAGVSERTIDPKQNFYMHWC"
+
+    def dataset(n_batches):
+        n = n_batches * batch
+        seqs = ["".join(aas[i] for i in torch.randint(0, 20, (args.seq_len,), generator=g).tolist()) for _ in range(n)]
+        return esm.FastaBatchedDataset([f"rank{rank}/s{i}" for i in range(n)], seqs)
+
+    alphabet = esm.Alphabet.from_architecture("ESM-1b")
+    fwd = make_embed_fn(model, varlen=True)
+    base = args.out_dir or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
+    out_dir = pathlib.Path(tempfile.mkdtemp(prefix="esm_amd_bench_", dir=base))
+    include = ["mean", "per_tok"]
+
+    def run(ds):
+        extract(ds, alphabet, fwd, L, E, [L], include, output_dir=out_dir, toks_per_batch=batch * (args.seq_len + 2),
+                device=dev, gather_mean=False, log=lambda s: None, writer_threads=args.writer_threads)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    try:
+        warm, timed = dataset(max(args.warmup, 1)), dataset(args.steps)
+        run(warm)
+        sync_all()
+        t0 = time.perf_counter()
+        run(timed)  # returns after the writer threads have closed every file
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        n_files = sum(1 for _ in out_dir.rglob("*.pt"))
+        nbytes = sum(p.stat().st_size for p in out_dir.rglob("*.pt"))
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+    value = world * batch * args.seq_len * args.steps / elapsed
+    if rank != 0:
+        return None
+    result = base_result(
+        args, world, "residues/sec ESM-2 650M L=1022 extraction driver, result files written", value, elapsed,
+        "esm_amd.extract.extract on synthetic FASTA strings: tokenise -> esm2_t33_650M forward -> device->host -> "
+        "one .pt per sequence (--include mean per_tok, reference file format)",
+        {"batch_per_gpu": batch, "seq_len": args.seq_len, "output_fs": str(base),
+         "writer_threads": args.writer_threads or default_writer_threads()})
+    result["files_written_this_rank"] = n_files
+    result["file_gb_per_s_this_rank"] = round(nbytes / elapsed / 1e9 * args.steps / (args.steps + max(args.warmup, 1)), 3)
+    result["e2e_mfma_frac_per_gpu"] = round(value / world * 1.4769e9 / (MFMA_PEAK_TFLOPS * 1e12), 4)
+    result["roofline"] = None   # a host + PCIe + file-system pipeline: the forward's roofline is the esm2_650m line
+    result["library"] = library_build()
+    return result
+
+
+WORKLOADS = {"esm2_650m": run_esm2_650m, "esm2_3b_contacts": run_esm2_3b_contacts, "msa1b": run_msa1b,
+             "extract_650m": run_extract_650m}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="esm2_650m")
+    ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (0 = the workload's default: 64 "
+                                                         "sequences for esm2_650m, 16 for esm2_3b_contacts, 1 MSA)")
+    ap.add_argument("--seq-len", type=int, default=1022)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--out-dir", default=None, help="extract_650m: directory (file system) the result files go to")
+    ap.add_argument("--writer-threads", type=int, default=0, help="extract_650m: writer threads (0 = from host cores)")
+    ap.add_argument("--spawn", action="store_true",
+                    help="go through the self-launch path even for --gpus 1 (tests: the N = 1 run then initialises RCCL "
+                         "exactly as an N > 1 run does)")
+    ap.add_argument("--protocol-test", action="store_true",
+                    help="CPU/gloo dry run of the launch + timing protocol with a stub step (tests/test_bench_protocol.py); "
+                         "never a measurement")
+    args = ap.parse_args()
+
+    from esm_amd.launch import init_ranks, relaunch, under_launcher
+
+    if (args.gpus > 1 or args.spawn) and not under_launcher():
+        os.environ["ESM_AMD_BENCH_LAUNCH"] = "self-spawned"
+        raise SystemExit(relaunch(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    if args.protocol_test:
+        if args.batch == 0:
+            args.batch = 64
+        return protocol_test(args)
+
+    dist, rank, world, local_rank = init_ranks(args.gpus, "nccl")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    result = WORKLOADS[args.workload](args, dist, rank, world, dev)
+    if rank == 0:
+        result["collective_backend"] = dist.get_backend() if dist is not None else None
         print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(dist)
 
 
 if __name__ == "__main__":

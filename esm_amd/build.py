@@ -1,10 +1,13 @@
 """Build libesmk.so (the gfx950 HIP engine) in-tree with hipcc.
 
-    python -m esm_amd.build            # builds esm_amd/lib/libesmk.so if sources are newer
+    python -m esm_amd.build            # builds esm_amd/lib/libesmk.so unless it was built from these sources
 
 hipcc cross-compiles for gfx950 without a GPU; the resulting .so is git-ignored but travels
-with the source tree to the GPU box.
+with the source tree to the GPU box.  The library carries the SHA-256 of the sources it was compiled from
+(``esmk_version()`` -> "... src:<16 hex>"); ``needs_build`` compares that with the sources on disk, not mtimes,
+and ``__graft_entry__.build`` / ``bench.py`` read it back through the C ABI.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -26,12 +29,32 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libesmk.so cannot be built")
 
 
+_MARK = b"esmk-src:"
+
+
+def source_hash():
+    """First 16 hex digits of the SHA-256 over every source and header (names and contents) and the flags."""
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in SOURCES + HEADERS:
+        h.update(os.path.basename(f).encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def library_hash(path=LIB):
+    """The source hash embedded in a built libesmk.so (read from the file, no dlopen), or None."""
+    try:
+        with open(path, "rb") as fh:
+            blob = fh.read()
+    except OSError:
+        return None
+    i = blob.find(_MARK)
+    return blob[i + len(_MARK): i + len(_MARK) + 16].decode("ascii", "replace") if i >= 0 else None
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return library_hash() != source_hash()
 
 
 def build(force=False, verbose=True):
@@ -39,11 +62,14 @@ def build(force=False, verbose=True):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
+    srchash = source_hash()
     objs = []
     procs = []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if src == "engine.hip":
+            cmd.insert(-4, f'-DESMK_SRC_HASH="{srchash}"')
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -58,6 +84,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    if library_hash() != srchash:
+        raise RuntimeError("libesmk.so does not carry the hash of the sources it was just built from")
     return LIB
 
 

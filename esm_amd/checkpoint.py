@@ -85,12 +85,23 @@ def has_emb_layer_norm_before(model_state):
     return any(k.startswith("emb_layer_norm_before") for k in model_state)
 
 
-_PREFIX = re.compile(r"^(encoder\.sentence_encoder\.|encoder\.)")
+_PREFIX = re.compile(r"^(encoder\.sentence_encoder\.|encoder\.|sentence_encoder\.)")
+_ARG_PREFIX = re.compile(r"^encoder_")
+
+
+def strip_key_prefix(key):
+    """'encoder.sentence_encoder.layers.0.fc1.weight' / 'encoder.lm_head.bias' -> module-relative key."""
+    return _PREFIX.sub("", key)
+
+
+def strip_arg_prefix(name):
+    """'encoder_embed_dim' -> 'embed_dim' (hyper-parameter names of the v1 checkpoints)."""
+    return _ARG_PREFIX.sub("", name)
 
 
 def _build_esm2(model_data):
     cfg = model_data["cfg"]["model"]
-    state = {_PREFIX.sub("", k): v for k, v in model_data["model"].items()}
+    state = {strip_key_prefix(k): v for k, v in model_data["model"].items()}
     alphabet = Alphabet.from_architecture("ESM-1b")
     model = ESM2(
         num_layers=cfg.encoder_layers,

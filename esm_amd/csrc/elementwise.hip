@@ -540,6 +540,66 @@ hipError_t launch_copy_f32(const float* src, float* dst, size_t n, hipStream_t s
 }
 
 // ---------------------------------------------------------------------------------------------
+// Mean over the residue rows of every sequence — reference scripts/extract.py:113-116
+// (`t[i, 1 : truncate_len + 1].mean(0)`): out[b, e] = mean of x[b, first .. first + cnt_b), cnt_b =
+// min(count[b], T - first); an empty slice gives NaN as torch.mean does.  Workgroup = (256-column slab,
+// sequence): the four waves each sum a quarter of the rows (16 B per lane, whole 1-KiB / 512-B row segments),
+// then combine through LDS in wave order — deterministic, no atomics.  HBM bound: reads the tensor once.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void masked_row_mean_kernel(const T* __restrict__ x, const int* __restrict__ count,
+                                                              float* __restrict__ out, int T_rows, int E, int first) {
+    __shared__ f32x4 part[4][64];
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 256 + lane * 4;
+    int cnt = count[b];
+    cnt = cnt < 0 ? 0 : (cnt > T_rows - first ? T_rows - first : cnt);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (col < E) {
+        const T* base = x + ((size_t)b * T_rows + first) * E + col;
+        for (int r = wave; r < cnt; r += 4) {
+            const T* p = base + (size_t)r * E;
+            if constexpr (sizeof(T) == 4) {
+                const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+                acc += v;
+            } else {
+                typename Op<T>::v4 v = *reinterpret_cast<const typename Op<T>::v4*>(p);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] += (float)v[i];
+            }
+        }
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && col < E) {
+        f32x4 s = part[0][lane];
+        s += part[1][lane];
+        s += part[2][lane];
+        s += part[3][lane];
+        const float inv = 1.0f / (float)cnt;  // cnt == 0: 0 * inf = NaN, the mean of an empty slice
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = s[i] * inv;
+        *reinterpret_cast<f32x4*>(out + (size_t)b * E + col) = o;
+    }
+}
+
+hipError_t launch_masked_row_mean(const void* x, int x_dtype, const int* count, float* out, int B, int T, int E,
+                                  int first, hipStream_t st) {
+    if (E % 4 != 0 || B <= 0 || T <= 0 || first < 0 || first > T) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((E + 255) / 256), (unsigned)B);
+    if (x_dtype == ESMK_DT_F32)
+        hipLaunchKernelGGL(masked_row_mean_kernel<float>, grid, dim3(256), 0, st, (const float*)x, count, out, T, E, first);
+    else if (x_dtype == ESMK_DT_F16)
+        hipLaunchKernelGGL(masked_row_mean_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16*)x, count, out, T, E, first);
+    else if (x_dtype == ESMK_DT_BF16)
+        hipLaunchKernelGGL(masked_row_mean_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, count, out, T, E, first);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // RoPE tables — reference esm/rotary_embedding.py:47-61: t = arange(T) (fp32), freqs = t x
 // inv_freq (fp32 product), cos/sin in fp32.  Only the d/2 distinct columns are stored (the
 // reference duplicates them with cat(freqs, freqs)).

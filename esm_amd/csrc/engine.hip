@@ -188,35 +188,6 @@ int ensure_unit_rope(esmk_model* m, int T, hipStream_t st) {
 
 namespace {
 
-enum {
-    PC_EMBED = 0, PC_LAYERNORM, PC_GEMM_QKV, PC_ATTENTION, PC_ATTN_PROBS, PC_GEMM_OUT, PC_GEMM_FC1,
-    PC_GEMM_FC2, PC_COPY, PC_LM_DENSE, PC_LM_LOGITS, PC_CONTACTS, PC_COUNT
-};
-const char* const kProfNames[PC_COUNT] = {
-    "embed", "layernorm", "gemm_qkv_rope", "attention", "attention_probs", "gemm_out_proj",
-    "gemm_fc1_gelu", "gemm_fc2", "repr_copy", "lm_head_dense", "lm_head_logits", "contacts"};
-
-// Brackets one launch with two events on the launch stream when profiling is enabled.
-struct ProfScope {
-    esmk_model* m;
-    hipStream_t st;
-    bool on;
-    ProfScope(esmk_model* m_, hipStream_t st_, int cls, double flops, double bytes)
-        : m(m_), st(st_), on(m_->prof_on) {
-        if (!on) return;
-        esmk_model::ProfRec r{cls, nullptr, nullptr, flops, bytes};
-        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
-            on = false;
-            return;
-        }
-        (void)hipEventRecord(r.a, st);
-        m->prof.push_back(r);
-    }
-    ~ProfScope() {
-        if (on) (void)hipEventRecord(m->prof.back().b, st);
-    }
-};
-
 bool starts_with(const char* s, const char* p) { return strncmp(s, p, strlen(p)) == 0; }
 
 size_t numel(const int64_t* shape, int ndim) {
@@ -230,7 +201,11 @@ size_t numel(const int64_t* shape, int ndim) {
 extern "C" {
 
 const char* esmk_last_error(void) { return g_err.c_str(); }
-const char* esmk_version(void) { return "esmk 0.1 (gfx950)"; }
+#ifndef ESMK_SRC_HASH
+#define ESMK_SRC_HASH "unhashed-build---"
+#endif
+// "esmk-src:" + the SHA-256 prefix of the sources (esm_amd/build.py: source_hash) — also read straight from the file
+const char* esmk_version(void) { return "esmk 0.2 (gfx950) esmk-src:" ESMK_SRC_HASH; }
 
 int esmk_create(const esmk_config* cfg, esmk_model** out) {
     if (!cfg || !out) return fail("esmk_create: null argument");
@@ -415,6 +390,7 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
 
 int esmk_workspace_bytes(const esmk_model* m, int B, int T, uint32_t out_flags, size_t* bytes) {
     if (!m || !bytes) return fail("esmk_workspace_bytes: null argument");
+    if (m->is_msa) return fail("esmk_workspace_bytes: MSA handle (use esmk_msa_workspace_bytes)");
     if (B <= 0 || T <= 0) return fail("esmk_workspace_bytes: B and T must be positive");
     if ((long long)B * T > ESMK_MAX_ROWS) return fail("esmk_workspace_bytes: B*T exceeds 2^24 rows");
     *bytes = plan_workspace(m, B, T, out_flags).total;
@@ -471,6 +447,7 @@ static int check_segments(const char* who, const esmk_model* m, const int32_t* s
 
 int esmk_packed_workspace_bytes(const esmk_model* m, int n_seg, int rows, uint32_t out_flags, size_t* bytes) {
     if (!m || !bytes) return fail("esmk_packed_workspace_bytes: null argument");
+    if (m->is_msa) return fail("esmk_packed_workspace_bytes: not an ESM-2 handle");
     if (n_seg <= 0 || rows <= 0 || rows % 64 != 0 || rows > ESMK_MAX_ROWS)
         return fail("esmk_packed_workspace_bytes: need n_seg > 0 and 0 < rows <= 2^24, rows % 64 == 0");
     if (out_flags & ~(uint32_t)(ESMK_OUT_LOGITS | ESMK_OUT_REPR_LOWP))
@@ -497,6 +474,7 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
                         void* contacts_out_dev, void* workspace_dev, size_t workspace_bytes,
                         void* stream, const PackedCtx* pc) {
     if (!m || !packed_dev || !tokens_dev || !workspace_dev) return fail("esmk_forward: null argument");
+    if (m->is_msa) return fail("esmk_forward: MSA handle (use esmk_msa_forward)");
     if (B <= 0 || T <= 0) return fail("esmk_forward: B and T must be positive");
     if ((long long)B * T > ESMK_MAX_ROWS) return fail("esmk_forward: B*T exceeds 2^24 rows");
     if (n_repr > 0 && (!repr_layers || !repr_out_dev)) return fail("esmk_forward: null repr arrays");
@@ -863,6 +841,17 @@ int esmk_op_layernorm(const float* x_dev, const float* gamma_dev, const float* b
                       void* stream) {
     ESMK_TRY(launch_layernorm(x_dev, gamma_dev, beta_dev, y_dev, y32_dev, rows, E, operand_dtype,
                               (hipStream_t)stream));
+    return 0;
+}
+
+int esmk_op_masked_row_mean(const void* x_dev, int x_dtype, const int32_t* count_dev, float* out_dev, int B, int T,
+                            int E, int first_row, void* stream) {
+    if (!x_dev || !count_dev || !out_dev) return fail("esmk_op_masked_row_mean: null argument");
+    if (B <= 0 || T <= 0 || E <= 0 || E % 4 != 0 || first_row < 0 || first_row > T)
+        return fail("esmk_op_masked_row_mean: need B, T > 0, E a positive multiple of 4, 0 <= first_row <= T");
+    if (x_dtype != ESMK_DT_F32 && x_dtype != ESMK_DT_F16 && x_dtype != ESMK_DT_BF16)
+        return fail("esmk_op_masked_row_mean: x_dtype must be ESMK_F32, ESMK_F16 or ESMK_BF16");
+    ESMK_TRY(launch_masked_row_mean(x_dev, x_dtype, count_dev, out_dev, B, T, E, first_row, (hipStream_t)stream));
     return 0;
 }
 

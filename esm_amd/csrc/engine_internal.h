@@ -88,6 +88,37 @@ struct esmk_model {
     int unit_cap = 0;
 };
 
+// ---- per-kernel-class timing (esmk_profile_begin / _end): classes of both engines ---------------------------
+enum {
+    PC_EMBED = 0, PC_LAYERNORM, PC_GEMM_QKV, PC_ATTENTION, PC_ATTN_PROBS, PC_GEMM_OUT, PC_GEMM_FC1,
+    PC_GEMM_FC2, PC_COPY, PC_LM_DENSE, PC_LM_LOGITS, PC_CONTACTS,
+    PC_MSA_ROW_SCORES, PC_MSA_ROW_SOFTMAX, PC_MSA_ROW_CTX, PC_MSA_COL_ATTN, PC_COUNT
+};
+static const char* const kProfNames[PC_COUNT] = {
+    "embed", "layernorm", "gemm_qkv_rope", "attention", "attention_probs", "gemm_out_proj",
+    "gemm_fc1_gelu", "gemm_fc2", "repr_copy", "lm_head_dense", "lm_head_logits", "contacts",
+    "msa_row_scores", "msa_row_softmax", "msa_row_context", "msa_col_attention"};
+
+// Brackets one launch with two events on the launch stream when profiling is enabled.
+struct ProfScope {
+    esmk_model* m;
+    hipStream_t st;
+    bool on;
+    ProfScope(esmk_model* m_, hipStream_t st_, int cls, double flops, double bytes)
+        : m(m_), st(st_), on(m_->prof_on) {
+        if (!on) return;
+        esmk_model::ProfRec r{cls, nullptr, nullptr, flops, bytes};
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+            on = false;
+            return;
+        }
+        (void)hipEventRecord(r.a, st);
+        m->prof.push_back(r);
+    }
+    ~ProfScope() {
+        if (on) (void)hipEventRecord(m->prof.back().b, st);
+    }
+};
 
 namespace esmk_host {
 // "unit" rotary tables (cos = 1, sin = 0) for models without RoPE (MSA Transformer, ESM-1b)

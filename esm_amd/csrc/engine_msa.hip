@@ -201,26 +201,41 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
     void* probs = ws + w.probs;
     if (ensure_unit_rope(m, std::max(R, C), st)) return 1;
 
+    const double NE = (double)N * E;
     auto repr_copy = [&](int layer, const float* src) -> int {
         for (int i = 0; i < n_repr; ++i)
-            if (repr_layers[i] == layer)
+            if (repr_layers[i] == layer) {
+                ProfScope ps(m, st, PC_COPY, 0, 8 * NE);
                 ESMK_TRY(launch_copy_f32(src, (float*)repr_out_dev[i], (size_t)N * E, st));
+            }
         return 0;
     };
-    auto gemm = [&](const GemmArgs& a, int epi) -> int {
+    // algorithmic work of one (batched) GEMM launch: operands read once, result written once
+    auto gemm = [&](int cls, const GemmArgs& a, int epi, double out_bytes_per_elem) -> int {
+        const double z = a.batch > 0 ? a.batch : 1;
+        const double fl = 2.0 * z * a.M * (double)(a.n_valid ? a.n_valid : a.N) * a.K;
+        const double by = z * (((double)a.M * a.K + (double)a.N * a.K) * os + (double)a.M * a.N * out_bytes_per_elem);
+        ProfScope ps(m, st, cls, fl, by);
         ESMK_TRY(launch_gemm(a, epi, op, st));
+        return 0;
+    };
+    auto lnorm = [&](const float* in, size_t go, size_t bo, void* y, float* y32, LnExtra ex) -> int {
+        ProfScope ps(m, st, PC_LAYERNORM, 8 * NE, NE * (4 + (y ? os : 0) + (y32 ? 4 : 0)));
+        ESMK_TRY(launch_layernorm_ex(in, (const float*)(pk + go), (const float*)(pk + bo), y, y32, N, E, op, ex, st));
         return 0;
     };
 
     // msa_transformer.py:152-172: token + position + MSA-row embeddings, LayerNorm, pads zeroed
-    ESMK_TRY(launch_msa_embed(tokens_dev, (const float*)(pk + m->embed_f32), (const float*)(pk + m->pos_emb),
-                              m->has_msa_pos ? (const float*)(pk + m->msa_pos) : nullptr, x, keep, col_fill,
-                              any_pad, B, R, C, E, m->V, m->cfg.pad_idx, m->npos, st));
+    {
+        ProfScope ps(m, st, PC_EMBED, 0, (double)N * 8 + 4 * NE);
+        ESMK_TRY(launch_msa_embed(tokens_dev, (const float*)(pk + m->embed_f32), (const float*)(pk + m->pos_emb),
+                                  m->has_msa_pos ? (const float*)(pk + m->msa_pos) : nullptr, x, keep, col_fill,
+                                  any_pad, B, R, C, E, m->V, m->cfg.pad_idx, m->npos, st));
+    }
     {
         LnExtra ex;
         ex.row_keep = keep;
-        ESMK_TRY(launch_layernorm_ex(x, (const float*)(pk + m->lnb_g), (const float*)(pk + m->lnb_b), nullptr, x,
-                                     N, E, op, ex, st));
+        if (lnorm(x, m->lnb_g, m->lnb_b, nullptr, x, ex)) return 1;
     }
     if (repr_copy(0, x)) return 1;
 
@@ -244,13 +259,13 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
         g.Tp = Tp;
         g.scaling = scaling;
         g.row_keep = row_keep;
-        if (gemm(g, EPI_QKV_ROPE)) return 1;
+        if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;
         g.row_keep = nullptr;
         g.W = pk + a.wqkv + (size_t)2 * E * E * os;
         g.bias = (const float*)(pk + a.bqkv) + 2 * E;
         g.N = E;
         g.vt_rows = vt_rows;
-        return gemm(g, EPI_V_T);
+        return gemm(PC_GEMM_QKV, g, EPI_V_T, os);
     };
     auto out_proj = [&](const AttnOff& a, int map_R, int map_C) -> int {
         GemmArgs g;
@@ -263,14 +278,13 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
         g.K = E;
         g.rowmap_R = map_R;
         g.rowmap_C = map_C;
-        return gemm(g, EPI_RESID_F32);
+        return gemm(PC_GEMM_OUT, g, EPI_RESID_F32, 8);
     };
 
     for (int l = 0; l < L; ++l) {
         const MsaLayerOff& o = m->mlayer[l];
         // ---- tied row attention (axial_attention.py:75-130; NormalizedResidualBlock modules.py:376-392) ----
-        ESMK_TRY(launch_layernorm(x, (const float*)(pk + o.row.lng), (const float*)(pk + o.row.lnb), h, nullptr, N,
-                                  E, op, st));
+        if (lnorm(x, o.row.lng, o.row.lnb, h, nullptr, LnExtra())) return 1;
         if (Cp != C) ESMK_TRY(hipMemsetAsync(vt, 0, (size_t)B * H * R * 64 * Cp * os, st));
         // sequences = MSA rows (b,r) of C tokens; q scaled by d^-1/2 / sqrt(R) (axial_attention.py:36-38)
         if (qkv(o.row, C, Cp, (1.0f / sqrtf(64.0f)) / sqrtf((float)R), keep, R)) return 1;
@@ -293,10 +307,15 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
             g.a_bi = g.w_bi = (long long)C * 64 * os;
             g.o_bo = (long long)H * C * Cp * 4;
             g.o_bi = (long long)C * Cp * 4;
-            if (gemm(g, EPI_STORE_F32)) return 1;
+            if (gemm(PC_MSA_ROW_SCORES, g, EPI_STORE_F32, 4)) return 1;
         }
-        ESMK_TRY(launch_msa_row_softmax(scores, keep, any_pad, probs, want_attn ? (float*)row_attn_out_dev : nullptr,
-                                        B, H, R, C, Cp, l, L, op, st));
+        {
+            const double sc = (double)B * H * C * C;
+            ProfScope ps(m, st, PC_MSA_ROW_SOFTMAX, 0, sc * (4 + os + (want_attn ? 4 : 0)));
+            ESMK_TRY(launch_msa_row_softmax(scores, keep, any_pad, probs,
+                                            want_attn ? (float*)row_attn_out_dev : nullptr, B, H, R, C, Cp, l, L, op,
+                                            st));
+        }
         {   // context[r,i,b,h,:] = sum_j probs[h,b,i,j] v[r,j,b,h,:]   (axial_attention.py:111)
             GemmArgs g;
             g.A = probs;
@@ -315,7 +334,7 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
             g.w_bi = (long long)R * 64 * Cp * os;
             g.ctx_R = R;
             g.ctx_C = C;
-            if (gemm(g, EPI_MSA_CTX)) return 1;
+            if (gemm(PC_MSA_ROW_CTX, g, EPI_MSA_CTX, os)) return 1;
         }
         if (out_proj(o.row, 0, 0)) return 1;
 
@@ -325,20 +344,24 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
             LnExtra ex;
             ex.map_R = R;
             ex.map_C = C;
-            ESMK_TRY(launch_layernorm_ex(x, (const float*)(pk + o.col.lng), (const float*)(pk + o.col.lnb), h, nullptr,
-                                         N, E, op, ex, st));
+            if (lnorm(x, o.col.lng, o.col.lnb, h, nullptr, ex)) return 1;
         }
         if (Rp != R) ESMK_TRY(hipMemsetAsync(vt, 0, (size_t)B * C * H * 64 * Rp * os, st));
         if (qkv(o.col, R, Rp, 1.0f / sqrtf(64.0f), nullptr, 0)) return 1;
         float* lse = want_col ? (float*)(ws + w.lse) : nullptr;
-        ESMK_TRY(launch_attention_fill(q, k, vt, col_fill, any_pad, h, lse, B * C, H, R, Rp, op, st));
-        if (want_col)
+        {
+            ProfScope ps(m, st, PC_MSA_COL_ATTN, 4.0 * N * (double)R * E, 4 * NE * os);
+            ESMK_TRY(launch_attention_fill(q, k, vt, col_fill, any_pad, h, lse, B * C, H, R, Rp, op, st));
+        }
+        if (want_col) {
+            ProfScope ps(m, st, PC_ATTN_PROBS, 2.0 * N * (double)R * E, 2 * NE * os + 4.0 * N * R * H);
             ESMK_TRY(launch_attention_probs_msa(q, k, lse, col_fill, any_pad, (float*)col_attn_out_dev, B, C, H, R, l,
                                                 L, op, st));
+        }
         if (out_proj(o.col, R, C)) return 1;
 
         // ---- feed forward (modules.py:395-418) ----
-        ESMK_TRY(launch_layernorm(x, (const float*)(pk + o.flng), (const float*)(pk + o.flnb), h, nullptr, N, E, op, st));
+        if (lnorm(x, o.flng, o.flnb, h, nullptr, LnExtra())) return 1;
         {
             GemmArgs g;
             g.A = h;
@@ -348,7 +371,7 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
             g.M = N;
             g.N = F;
             g.K = E;
-            if (gemm(g, EPI_GELU_T)) return 1;
+            if (gemm(PC_GEMM_FC1, g, EPI_GELU_T, os)) return 1;
             g = GemmArgs();
             g.A = ffn;
             g.W = pk + o.w2;
@@ -357,7 +380,7 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
             g.M = N;
             g.N = E;
             g.K = F;
-            if (gemm(g, EPI_RESID_F32)) return 1;
+            if (gemm(PC_GEMM_FC2, g, EPI_RESID_F32, 8)) return 1;
         }
         if (l + 1 < L && repr_copy(l + 1, x)) return 1;  // msa_transformer.py:197-198
     }
@@ -371,8 +394,7 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
             if (!rep_last) rep_last = (float*)repr_out_dev[i];
         }
     if (want_logits || wants_last) {
-        ESMK_TRY(launch_layernorm(x, (const float*)(pk + m->fin_g), (const float*)(pk + m->fin_b),
-                                  want_logits ? h : nullptr, rep_last, N, E, op, st));
+        if (lnorm(x, m->fin_g, m->fin_b, want_logits ? h : nullptr, rep_last, LnExtra())) return 1;
         for (int i = 0; i < n_repr; ++i)
             if (repr_layers[i] == L && repr_out_dev[i] != rep_last)
                 ESMK_TRY(launch_copy_f32(rep_last, (float*)repr_out_dev[i], (size_t)N * E, st));
@@ -386,9 +408,8 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
         g.M = N;
         g.N = E;
         g.K = E;
-        if (gemm(g, EPI_GELU_F32)) return 1;
-        ESMK_TRY(launch_layernorm(g32, (const float*)(pk + m->lm_lng), (const float*)(pk + m->lm_lnb), h, nullptr, N, E,
-                                  op, st));
+        if (gemm(PC_LM_DENSE, g, EPI_GELU_F32, 4)) return 1;
+        if (lnorm(g32, m->lm_lng, m->lm_lnb, h, nullptr, LnExtra())) return 1;
         g = GemmArgs();
         g.A = h;
         g.W = pk + m->embed_op;
@@ -397,10 +418,11 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
         g.M = N;
         g.N = m->V;
         g.K = E;
-        if (gemm(g, EPI_STORE_F32)) return 1;
+        if (gemm(PC_LM_LOGITS, g, EPI_STORE_F32, 4)) return 1;
     }
     if (want_contacts) {  // msa_transformer.py:215-217 -> modules.py:338-357 on the row attentions
         // the contact head reads tokens only for the <eos> mask, which the MSA alphabet does not append
+        ProfScope ps(m, st, PC_CONTACTS, 0, 2.0 * 4 * B * (double)L * H * C * C);
         ESMK_TRY(launch_contacts((const float*)row_attn_out_dev, tokens_dev, (const float*)(pk + m->ct_w),
                                  (const float*)(pk + m->ct_b), (float*)(ws + w.ct_scratch),
                                  (float*)contacts_out_dev, B, L * H, C, m->cfg.eos_idx, m->cfg.prepend_bos,

@@ -106,6 +106,9 @@ hipError_t launch_convert2d(const void* src, int src_dtype, void* dst, int dst_d
 hipError_t launch_rope_table(const float* inv_freq, float* cos, float* sin, int T, int half,
                              hipStream_t st);
 hipError_t launch_copy_f32(const float* src, float* dst, size_t n, hipStream_t st);
+// out[b,:] = mean of rows [first, first + min(count[b], T - first)) of x[b] ([B,T,E], any dtype code); NaN if empty
+hipError_t launch_masked_row_mean(const void* x, int x_dtype, const int* count, float* out, int B, int T, int E,
+                                  int first, hipStream_t st);
 // contact head (modules.py:27-41,338-357)
 hipError_t launch_contacts(const float* attn, const int64_t* tokens, const float* w,
                            const float* b, float* scratch, float* out, int B, int C, int T,

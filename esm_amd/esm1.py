@@ -89,13 +89,13 @@ def build_from_checkpoint(model_data):
     import argparse
 
     from .alphabet import Alphabet
+    from .checkpoint import strip_arg_prefix, strip_key_prefix
 
     alphabet = Alphabet.from_architecture(model_data["args"].arch)
-    pra = lambda s: "".join(s.split("encoder_")[1:] if "encoder" in s else s)
-    prs1 = lambda s: "".join(s.split("encoder.")[1:] if "encoder" in s else s)
-    prs2 = lambda s: "".join(s.split("sentence_encoder.")[1:] if "sentence_encoder" in s else s)
-    model_args = {pra(k): v for k, v in vars(model_data["args"]).items()}
-    state = {prs1(prs2(k)): v for k, v in model_data["model"].items()}
+    # fairseq-era checkpoints: hyper-parameters are "encoder_<name>", tensors "encoder.sentence_encoder.<key>" /
+    # "encoder.<key>" 
+    model_args = {strip_arg_prefix(k): v for k, v in vars(model_data["args"]).items()}
+    state = {strip_key_prefix(k): v for k, v in model_data["model"].items()}
     state["embed_tokens.weight"][alphabet.mask_idx].zero_()  # for token dropout (pretrained.py:97)
     model_args["emb_layer_norm_before"] = any(k.startswith("emb_layer_norm_before") for k in state)
     model = ProteinBertModel(argparse.Namespace(**model_args), alphabet)

@@ -9,6 +9,7 @@ pointers to ``esmk_forward`` (include/esmk.h).  There is no CPU path: CPU tensor
 """
 import ctypes
 import os
+import warnings
 from typing import Union
 
 import torch
@@ -100,6 +101,34 @@ def _operand_dtype_for(param_dtype):
     return torch.bfloat16 if param_dtype == torch.bfloat16 else torch.float16
 
 
+def live_tensors(engine, model, skip):
+    """[(state-dict key, tensor)] of the model's CURRENT parameters and buffers.  The (owner dict, name) slots are
+    collected once per engine; reading them back costs a dict lookup per tensor, so a replaced Parameter object is
+    picked up without walking the module tree on every forward."""
+    if engine._named is None:
+        slots = []
+        for prefix, mod in model.named_modules():
+            for store in (mod._parameters, mod._buffers):
+                for name, t in store.items():
+                    key = f"{prefix}.{name}" if prefix else name
+                    if t is not None and not skip(key) and name not in getattr(mod, "_non_persistent_buffers_set", ()):
+                        slots.append((key, store, name))
+        engine._named = slots
+    return [(key, store[name]) for key, store, name in engine._named]
+
+
+def warn_if_grad_expected(model):
+    """The engine is forward-only: outputs carry no grad_fn.  The reference's own tests call forward without
+    ``no_grad`` (tests/test_load_all.py:39-47), so this warns — once per model — instead of raising."""
+    if torch.is_grad_enabled() and not getattr(model, "_warned_no_grad", False):
+        if any(p.requires_grad for p in model.parameters()):
+            warnings.warn(
+                "esm_amd: the MI355X engine is forward-only — the tensors returned by forward() have no grad_fn, so "
+                "backward() through this model yields no parameter gradients. Wrap inference in torch.no_grad() or "
+                "call model.requires_grad_(False) to silence this warning.", RuntimeWarning, stacklevel=3)
+        object.__setattr__(model, "_warned_no_grad", True)
+
+
 class _Engine:
     """One esmk_model handle + packed parameter image + workspace for one (device, dtype)."""
 
@@ -156,14 +185,14 @@ class _Engine:
         return self.workspace
 
     def sync_weights(self, model):
-        """Re-pack the parameter image when any parameter storage or version changed
-        (``.cuda()``, ``.half()``, ``load_state_dict``, in-place edits)."""
+        """Re-pack the parameter image when the parameters changed: ``.cuda()`` / ``.half()`` /
+        ``load_state_dict`` (also with ``assign=True``), ``module.weight = nn.Parameter(...)``, swapped tensors and
+        tracked in-place edits are all seen (live tensors are looked up on every call; fingerprint = object id,
+        storage address, version counter, dtype).  NOT seen: writes through ``param.data`` (they bypass the version
+        counter) and replaced sub-modules — call ``model.refresh_engine()`` after those."""
         N = self.N
-        if self._named is None:  # Parameter objects persist across .cuda()/.half()/load_state_dict
-            self._named = [(k, t) for k, t in model.state_dict(keep_vars=True).items()
-                           if k != "lm_head.weight" and not k.endswith("inv_freq")]
-        named = self._named
-        fp = tuple((t.data_ptr(), t._version, t.dtype) for _, t in named)
+        named = live_tensors(self, model, skip=lambda k: k == "lm_head.weight" or k.endswith("inv_freq"))
+        fp = tuple((id(t), t.data_ptr(), t._version, t.dtype) for _, t in named)
         if fp == self.fingerprint:
             return
         stream = N.cur_stream()
@@ -255,6 +284,7 @@ class ESM2(nn.Module):
         w = self.embed_tokens.weight
         if w.device != tokens.device:
             raise RuntimeError(f"model parameters are on {w.device} but tokens on {tokens.device}")
+        warn_if_grad_expected(self)
         from . import _native as N
 
         dev = tokens.device
@@ -328,6 +358,7 @@ class ESM2(nn.Module):
         w = self.embed_tokens.weight
         if not w.is_cuda:
             raise RuntimeError("esm_amd.ESM2 runs only on an MI355X (ROCm) device; the engine has no CPU fallback")
+        warn_if_grad_expected(self)
         dev = w.device
         B, T = tokens.shape
         L, E, V = self.num_layers, self.embed_dim, self.alphabet_size

@@ -12,6 +12,7 @@ files: reference scripts/extract.py:15-131) and adds the data-parallel split of 
   one ``[n_sequences, E]`` matrix per layer in FASTA order.
 
     python -m esm_amd.extract model.pt seqs.fasta out/ --repr_layers 33 --include mean per_tok
+    python -m esm_amd.extract model.pt seqs.fasta out/ --repr_layers 33 --include mean --gpus 8   # spawns 8 ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
         -m esm_amd.extract model.pt seqs.fasta out/ --repr_layers 33 --include mean
 
@@ -22,6 +23,7 @@ import argparse
 import os
 import pathlib
 import queue
+import sys
 import threading
 from typing import Callable, Dict, List, Optional, Sequence
 
@@ -90,6 +92,14 @@ def gather_rows(local_rows: torch.Tensor, local_index: torch.Tensor, n_total: in
     return out
 
 
+def default_writer_threads() -> int:
+    """``torch.save`` of a 5 MB per-sequence result costs ~15-20 ms of host time (pickle + CRC32 + copy into the zip
+    container), almost all of it with the GIL released: writer THREADS scale (measured 29 -> 233 -> 368 files/s
+    with 1 / 2 / 4 threads on 8 busy cores), so the pool is sized from the host: 440 files/s keep one MI355X
+    busy at L = 1022."""
+    return max(2, min(24, (os.cpu_count() or 4) // 4))
+
+
 class _Writer:
     """Background result writer: the device->host copy of batch i (on its own HIP stream, into pinned
     buffers) and the slicing / ``torch.save`` of its sequences overlap the forward pass of batch i+1
@@ -156,14 +166,16 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
             embed_dim: int, repr_layers: Sequence[int], include: Sequence[str],
             output_dir: Optional[pathlib.Path] = None, toks_per_batch: int = 4096,
             truncation_seq_length: int = 1022, device: Optional[torch.device] = None,
-            gather_mean: bool = True, log: Callable[[str], None] = print):
+            gather_mean: bool = True, log: Callable[[str], None] = print, writer_threads: int = 0,
+            writer_depth: int = 4):
     """Run the sharded extraction.  ``embed_fn(tokens, repr_layers, return_contacts)`` is the model
     forward (``ESM2.__call__`` / ``ESM2.forward_varlen`` in production; an ``embed_fn.wants_lengths = True``
     attribute asks for the extra keyword ``lengths`` = per-row token counts, taken from the host copy).  Returns ``{layer: [n_sequences, E] mean embeddings}``
     in dataset order when ``gather_mean`` (every rank gets the full matrix), else ``{}``."""
     dist, rank, world = _dist_info()
     assert all(-(num_layers + 1) <= i <= num_layers for i in repr_layers)
-    layers = [(i + num_layers + 1) % (num_layers + 1) for i in repr_layers]
+    # duplicates (e.g. --repr_layers -1 33) collapse, first occurrence wins: the reference builds dicts keyed by layer
+    layers = list(dict.fromkeys((i + num_layers + 1) % (num_layers + 1) for i in repr_layers))
     return_contacts = "contacts" in include
     lengths = [min(len(s), truncation_seq_length) for s in dataset.sequence_strs]
     batches = dataset.get_batch_indices(toks_per_batch, extra_toks_per_seq=1)
@@ -177,14 +189,20 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
     lock = threading.Lock()
 
     def batch_means(reps, strs):
-        """mean over residues 1..n of every sequence as ONE batched matmul on the tensors' device
-        (mask [B,1,T] x reps [B,T,E]); a per-sequence ``mean(0)`` on the host costs ~20 ms per 1022 x 1280 slice."""
+        """`t[i, 1 : n+1].mean(0)` of every sequence (reference scripts/extract.py:113-116) for the whole batch on the
+        tensors' device: one pass of ``esmk_op_masked_row_mean`` per layer (csrc/elementwise.hip) on the GPU; a
+        per-sequence ``mean(0)`` on the host costs ~20 ms per 1022 x 1280 slice.  The slice is cut at the tensor's
+        end and an empty one gives NaN, as in the reference; the result has the dtype of the representations."""
         any_t = next(iter(reps.values()))
-        B, T = any_t.shape[0], any_t.shape[1]
-        n = torch.tensor([min(truncation_seq_length, len(s)) for s in strs], device=any_t.device)
-        pos = torch.arange(T, device=any_t.device)[None, :]
-        mask = ((pos >= 1) & (pos <= n[:, None])).to(torch.float32)[:, None, :]  # [B,1,T]
-        return {l: (torch.bmm(mask, t.float())[:, 0, :] / n[:, None].clamp(min=1).float()) for l, t in reps.items()}
+        n = torch.tensor([min(truncation_seq_length, len(s)) for s in strs], dtype=torch.int32)
+        if any_t.is_cuda:
+            from . import ops
+
+            n = n.to(any_t.device, non_blocking=True)
+            return {l: ops.masked_row_mean(t.contiguous(), n, first_row=1).to(t.dtype) for l, t in reps.items()}
+        # CPU tensors only reach this function in the gloo sharding tests (stub embed_fn), never on the product path
+        return {l: torch.stack([t[i, 1:int(k) + 1].float().mean(0) for i, k in enumerate(n)]).to(t.dtype)
+                for l, t in reps.items()}
 
     def finish(ids, labels, strs, reps, contacts, means_b):
         """Per-sequence results of one batch from HOST tensors (reference scripts/extract.py:104-131)."""
@@ -217,7 +235,7 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
                 my_means[l].extend(rows_mean[l])
 
     on_gpu = device is not None and device.type == "cuda"
-    writer = _Writer() if on_gpu else None
+    writer = _Writer(depth=writer_depth, threads=writer_threads or default_writer_threads()) if on_gpu else None
     pool = _PinnedPool() if on_gpu else None
     copy_stream = torch.cuda.Stream(device) if on_gpu else None
     with torch.no_grad():
@@ -275,7 +293,7 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
         dev = device if device is not None else torch.device("cpu")
         idx = torch.tensor(my_index, dtype=torch.int64, device=dev)
         for l in layers:
-            rows = (torch.stack(my_means[l]) if my_means[l] else torch.zeros((0, embed_dim))).to(dev).float()
+            rows = (torch.stack(my_means[l]).float() if my_means[l] else torch.zeros((0, embed_dim))).to(dev)
             gathered[l] = gather_rows(rows.reshape(-1, embed_dim), idx, len(dataset))
     return gathered
 
@@ -309,6 +327,13 @@ def create_parser():
     p.add_argument("--repr_layers", type=int, default=[-1], nargs="+")
     p.add_argument("--include", type=str, nargs="+", choices=["mean", "per_tok", "bos", "contacts"], required=True)
     p.add_argument("--truncation_seq_length", type=int, default=1022)
+    p.add_argument("--gpus", type=int, default=1,
+                   help="GPUs of this node to shard the FASTA over; from a plain shell the command re-executes itself "
+                        "as that many ranks (torch.distributed.run, RCCL), under a launcher it joins the existing ranks")
+    p.add_argument("--nogpu", action="store_true",
+                   help="accepted for command-line compatibility with scripts/extract.py and refused: the engine has "
+                        "no CPU path")
+    p.add_argument("--writer_threads", type=int, default=0, help="result-file writer threads (0 = from the host's cores)")
     p.add_argument("--no_varlen", action="store_true",
                    help="always run padded batches (default: token-packed batches whenever they save >= 8 %% of the rows)")
     p.add_argument("--mean_matrix", type=pathlib.Path, default=None,
@@ -319,21 +344,24 @@ def create_parser():
 def main(argv=None):
     args = create_parser().parse_args(argv)
     from . import FastaBatchedDataset, pretrained
+    from .launch import init_ranks, relaunch, under_launcher
+    from .msa_transformer import MSATransformer
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.nogpu:
+        raise SystemExit("esm_amd.extract: --nogpu is not available — the forward pass exists only as gfx950 kernels "
+                         "(use the reference's scripts/extract.py for a CPU run)")
+
+    if args.gpus > 1 and not under_launcher():  # plain shell: become N ranks, one per GPU
+        raise SystemExit(relaunch(args.gpus, ("-m", "esm_amd.extract"), sys.argv[1:] if argv is None else argv))
     if not torch.cuda.is_available():
         raise RuntimeError("esm_amd.extract needs an MI355X: the engine has no CPU fallback")
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    dist, rank, world, local_rank = init_ranks(world_env, "nccl")  # nccl == RCCL on ROCm
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29534")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
     model, alphabet = pretrained.load_model_and_alphabet(args.model_location)
+    if isinstance(model, MSATransformer):  # scripts/extract.py:66-69
+        raise ValueError("This script currently does not handle models with MSA input (MSA Transformer).")
     model = model.eval().to(dev)
     dataset = FastaBatchedDataset.from_file(args.fasta_file)
     if rank == 0:
@@ -344,13 +372,11 @@ def main(argv=None):
     means = extract(dataset, alphabet, embed_fn, model.num_layers, model.embed_dim, args.repr_layers, args.include,
                     output_dir=args.output_dir, toks_per_batch=args.toks_per_batch,
                     truncation_seq_length=args.truncation_seq_length, device=dev,
-                    gather_mean=args.mean_matrix is not None)
+                    gather_mean=args.mean_matrix is not None, writer_threads=args.writer_threads)
     if args.mean_matrix is not None and rank == 0:
         torch.save({"labels": dataset.sequence_labels, "mean_representations": {l: t.cpu() for l, t in means.items()}},
                    args.mean_matrix)
-    if world > 1:
-        import torch.distributed as dist
-
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

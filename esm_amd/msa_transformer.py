@@ -13,11 +13,15 @@ reference does (the latter is 58 GB in fp32 for a 12-layer 128x513 MSA: it fits 
 ``model.return_col_attentions = False`` to skip it, e.g. for ``predict_contacts`` on deep MSAs.
 """
 import ctypes
+import re
 
 import torch
 import torch.nn as nn
 
-from .esm2 import ContactPredictionHead, RobertaLMHead, _Container, _operand_dtype_for
+from .esm2 import (ContactPredictionHead, RobertaLMHead, _Container, _operand_dtype_for, live_tensors,
+                   warn_if_grad_expected)
+
+_AXIS = re.compile(r"row|column")
 
 
 class _AxialAttention(_Container):
@@ -100,14 +104,14 @@ class _MsaEngine:
             pass
 
     def sync_weights(self, model):
+        """See esm_amd.esm2._Engine.sync_weights (same detection rules; ``refresh_engine()`` after ``.data`` edits)."""
         N = self.N
-        if self._named is None:
-            self._named = [(k, t) for k, t in model.state_dict(keep_vars=True).items() if k != "lm_head.weight"]
-        fp = tuple((t.data_ptr(), t._version, t.dtype) for _, t in self._named)
+        named = live_tensors(self, model, skip=lambda k: k == "lm_head.weight")
+        fp = tuple((id(t), t.data_ptr(), t._version, t.dtype) for _, t in named)
         if fp == self.fingerprint:
             return
         stream = N.cur_stream()
-        for key, t in self._named:
+        for key, t in named:
             t = t.detach()
             if key == "msa_position_embedding":  # [1,1024,1,D] (or [1,1024,1,1] in the first release) -> [1024,D]
                 t = t.expand(1, t.shape[1], 1, model.args.embed_dim).reshape(t.shape[1], model.args.embed_dim)
@@ -205,6 +209,7 @@ class MSATransformer(nn.Module):
         w = self.embed_tokens.weight
         if w.device != tokens.device:
             raise RuntimeError(f"model parameters are on {w.device} but tokens on {tokens.device}")
+        warn_if_grad_expected(self)
         from . import _native as N
 
         dev = tokens.device
@@ -255,6 +260,17 @@ class MSATransformer(nn.Module):
     def predict_contacts(self, tokens):
         return self(tokens, return_contacts=True)["contacts"]
 
+    def profile_begin(self):
+        """Arm per-kernel-class HIP-event timing of the following forward calls (bench.py --workload msa1b)."""
+        from .esm2 import ESM2
+
+        ESM2.profile_begin(self)
+
+    def profile_end(self):
+        from .esm2 import ESM2
+
+        return ESM2.profile_end(self)
+
     def refresh_engine(self):
         if self._engine is not None:
             self._engine.close()
@@ -270,14 +286,14 @@ def build_from_checkpoint(model_data):
     """``{"args": Namespace(arch="msa_transformer", ...), "model": state}`` -> (model, alphabet), following
     reference esm/pretrained.py:111-127 (prefix stripping, embed_positions_msa_dim from the tensor)."""
     from .alphabet import Alphabet
+    from .checkpoint import strip_arg_prefix, strip_key_prefix
 
     args = model_data["args"]
-    pra = lambda s: "".join(s.split("encoder_")[1:] if "encoder" in s else s)
-    prs1 = lambda s: "".join(s.split("encoder.")[1:] if "encoder" in s else s)
-    prs2 = lambda s: "".join(s.split("sentence_encoder.")[1:] if "sentence_encoder" in s else s)
-    prs3 = lambda s: s.replace("row", "column") if "row" in s else s.replace("column", "row")
-    model_args = {pra(k): v for k, v in vars(args).items()}
-    state = {prs1(prs2(prs3(k))): v for k, v in model_data["model"].items()}
+    # the released checkpoints name the two axial attentions the other way round from the module attributes
+    # (pretrained.py:111-124): "row" <-> "column" in every tensor name, after the usual prefix stripping
+    swap_axes = lambda key: _AXIS.sub(lambda m: "column" if m.group(0) == "row" else "row", key)
+    model_args = {strip_arg_prefix(k): v for k, v in vars(args).items()}
+    state = {strip_key_prefix(swap_axes(k)): v for k, v in model_data["model"].items()}
     if model_args.get("embed_positions_msa", False):
         model_args["embed_positions_msa_dim"] = state["msa_position_embedding"].size(-1)
     import argparse

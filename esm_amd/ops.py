@@ -32,6 +32,18 @@ def layernorm(x, gamma, beta, operand_dtype=torch.float16, want_op=True, want_f3
     return y, y32
 
 
+def masked_row_mean(x, counts, first_row=1):
+    """out[b] = x[b, first_row : first_row + counts[b]].mean(0) in fp32 (reference scripts/extract.py:113-116);
+    x [B,T,E] fp32 / fp16 / bf16, counts int32 [B] on the same device.  Empty slices give NaN, as torch.mean."""
+    _req_cuda(x, counts)
+    assert x.dim() == 3 and counts.dtype == torch.int32 and counts.numel() == x.shape[0]
+    B, T, E = x.shape
+    out = torch.empty((B, E), dtype=torch.float32, device=x.device)
+    N.check(N.lib.esmk_op_masked_row_mean(N.ptr(x), N.dtype_code(x.dtype), N.ptr(counts), N.ptr(out), B, T, E,
+                                          first_row, N.cur_stream()))
+    return out
+
+
 def linear(a, w, bias=None, epilogue=N.EPI_STORE_T, out=None, force_generic=False, dbg=0, force_old=False,
            panel_c=0):
     """nn.Linear with fused epilogue: a [M,K], w [N,K] (both f16 or bf16), bias fp32 [N]."""

@@ -187,6 +187,13 @@ int esmk_op_layernorm(const float* x_dev, const float* gamma_dev, const float* b
                       void* y_dev, float* y32_dev, int rows, int E, int operand_dtype,
                       void* stream);
 
+/* Mean representation of every sequence of a batch, as scripts/extract.py:113-116 computes it on the host
+ * (`t[i, 1 : truncate_len + 1].mean(0)`): out[b,:] (fp32 [B,E]) = mean of rows [first_row, first_row + n_b) of
+ * x[b] ([B,T,E] in dtype code x_dtype), n_b = min(count_dev[b], T - first_row); an empty slice yields NaN like
+ * torch.mean.  One pass over x, deterministic (no atomics). */
+int esmk_op_masked_row_mean(const void* x_dev, int x_dtype, const int32_t* count_dev, float* out_dev, int B, int T,
+                            int E, int first_row, void* stream);
+
 /* nn.Linear: C[M,N] = A[M,K] . W[N,K]^T + bias, epilogue selected by `epilogue`:
  *   0 plain -> out operand dtype [M,N]           1 plain -> out fp32 [M,N]
  *   2 gelu (modules.py:17-24) -> operand dtype   3 gelu -> fp32

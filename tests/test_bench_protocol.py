@@ -25,6 +25,41 @@ def test_two_rank_protocol(tmp_path):
     assert abs(r["value"] - 2 * 64 * 1022 * 4 / (r["ms_per_step"] * 4e-3)) / r["value"] < 1e-3
 
 
+def test_self_spawned_two_rank_protocol(tmp_path):
+    """`python bench.py --gpus 2` from a plain shell (no external launcher): the script re-executes itself as two
+    ranks (esm_amd/launch.py), which is the form the driver's N > 1 runs may take."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["PYTHONPATH"] = ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--protocol-test"], capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["backend"] == "gloo" and r["launched_by"] == "self-spawned"
+    assert 9.5 <= r["ms_per_step"] < 1000, r
+
+
+def test_self_spawned_single_rank_goes_through_the_process_group(tmp_path):
+    """--spawn: the N = 1 run takes the same launcher + init_process_group + all-reduce path as N > 1."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["PYTHONPATH"] = ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--spawn", "--steps", "2", "--warmup", "0",
+                          "--protocol-test"], capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 1 and r["backend"] == "gloo" and r["launched_by"] == "self-spawned"
+
+
+def test_world_size_mismatch_is_refused(tmp_path):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1",
+           "--warmup", "0", "--protocol-test"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=300)
+    assert out.returncode != 0 and "does not match --gpus" in (out.stderr + out.stdout)
+
+
 def test_single_process_protocol():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "0",
                           "--protocol-test"], capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=ROOT),

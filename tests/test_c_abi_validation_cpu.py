@@ -107,3 +107,22 @@ def test_msa_flag_check():
     n = ctypes.c_size_t()
     assert N.lib.esmk_msa_workspace_bytes(h, 1, 4, 16, N.OUT_LOGITS, ctypes.byref(n)) == 0 and n.value > 0
     N.lib.esmk_destroy(h)
+
+
+def test_handle_kind_mix_up_is_rejected():
+    """An MSA handle passed to the ESM-2 entry points (and the other way round) is refused before anything is
+    indexed: esmk_forward on an MSA handle used to walk the empty ESM-2 layer table."""
+    cfg = N.EsmkMsaConfig(2, 128, 2, 256, 33, 1, 32, 0, 2, 1, 0, 1026, 1, N.dtype_code(torch.float16))
+    hm = ctypes.c_void_p()
+    assert N.lib.esmk_msa_create(ctypes.byref(cfg), ctypes.byref(hm)) == 0
+    n = ctypes.c_size_t()
+    assert N.lib.esmk_workspace_bytes(hm, 2, 64, N.OUT_LOGITS, ctypes.byref(n)) != 0 and "MSA handle" in err()
+    assert N.lib.esmk_packed_workspace_bytes(hm, 2, 128, N.OUT_LOGITS, ctypes.byref(n)) != 0 and "ESM-2 handle" in err()
+    layers = (ctypes.c_int32 * 1)(2)
+    outs = (ctypes.c_void_p * 1)(0x2000)
+    assert N.lib.esmk_forward(hm, FAKE, FAKE, 2, 16, layers, 1, outs, N.OUT_LOGITS, FAKE, None, None, FAKE,
+                              ctypes.c_size_t(1 << 40), None) != 0 and "MSA handle" in err()
+    N.lib.esmk_destroy(hm)
+    rc, h = make()
+    assert N.lib.esmk_msa_workspace_bytes(h, 1, 4, 16, N.OUT_LOGITS, ctypes.byref(n)) != 0 and "MSA model handle" in err()
+    N.lib.esmk_destroy(h)

@@ -1,0 +1,232 @@
+"""Parity at the FULL size of BASELINE configs 3 and 5, against fixtures produced by the reference implementation
+itself (tests/golden/make_golden_large.py -> tests/golden/large_*.pt; slim fixtures: full contact maps, strided
+slices of the representations, a few whole attention maps and seeded random projections of EVERY attention map).
+
+    config 3  esm2_t36_3B dims: contacts + representations[36] + logits at T = 258 and on a padded (1022, 300) batch
+    config 5  esm_msa1b_t12_100M dims, one 128 x 513 MSA: logits, representations[12], row / column attentions, contacts
+
+GPU tests compare the HIP engine with the fixtures; the CPU tests at the bottom pin the oracle to the same fixtures
+(the MSA one runs in the default CPU suite, the 3B one only with ESM_AMD_SLOW_TESTS=1: ~36 GB, minutes).
+
+Tolerances (DESIGN.md §2 quotes the measured values): 'rel' = max|diff| / max|ref| over the compared block.
+"""
+import importlib.util
+import os
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def _load_gen():
+    spec = importlib.util.spec_from_file_location("make_golden_large", os.path.join(GOLD, "make_golden_large.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+GEN = _load_gen()
+
+
+def fixture(name):
+    path = os.path.join(GOLD, f"large_{name}.pt")
+    assert os.path.exists(path), f"{path} missing: regenerate with tests/golden/make_golden_large.py"
+    return torch.load(path, weights_only=False)
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def logit(p):
+    return torch.logit(p.double().clamp(1e-12, 1 - 1e-12))
+
+
+def contact_report(c, cr):
+    """max probability error, max logit error where the reference is not saturated, and that error relative to
+    the reference's logit range (the north star's 'contact-head logits within 1e-3 rel')."""
+    c, cr = c.double().cpu(), cr.double().cpu()
+    z, zr = logit(c), logit(cr)
+    ok = zr.abs() < 12
+    zerr = (z - zr)[ok].abs().max().item()
+    return (c - cr).abs().max().item(), zerr, zerr / zr[ok].abs().max().item()
+
+
+def argmax_check(logits, ref_logits, mask=None):
+    err = (logits - ref_logits).abs().max().item()
+    top2 = ref_logits.topk(2, dim=-1).values
+    decided = (top2[..., 0] - top2[..., 1]) > 2 * err
+    same = logits.argmax(-1) == ref_logits.argmax(-1)
+    if mask is not None:
+        decided, same_m = decided & mask, same[mask]
+    else:
+        same_m = same
+    return same_m.float().mean().item(), bool(same[decided].all()), err
+
+
+# ------------------------------------------------------------------------------------------------------------
+# config 3: ESM-2 3B
+# ------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def model_3b():
+    import esm
+    from esm_amd.synth import synth_esm2_state_dict
+
+    fix = fixture("esm2_3b_T258")
+    d = fix["dims"]
+    sd = synth_esm2_state_dict(d["L"], d["E"], d["H"], seed=d["seed"])
+    chk = GEN.checksum(sd)
+    assert abs(chk - fix["weights_checksum"]) < 1e-6 * abs(chk), "synthetic weight generator drifted"
+    m = esm.ESM2(d["L"], d["E"], d["H"]).eval()
+    m.load_state_dict(sd)
+    del sd
+    return m.cuda()
+
+
+def _check_3b(model, name):
+    fix = fixture(name)
+    L = fix["dims"]["L"]
+    toks = fix["tokens"].to(torch.int64)
+    lengths = fix["lengths"]
+    assert torch.equal(toks, GEN.esm2_3b_tokens(name)[0])
+    with torch.no_grad():
+        out = model(toks.cuda(), repr_layers=[L], return_contacts=True)
+        fused = model.predict_contacts(toks.cuda())
+    got = GEN.slim_esm2({"logits": out["logits"], "representations": out["representations"],
+                         "contacts": out["contacts"]}, toks, lengths, L)
+    fz = GEN.slim_esm2({"logits": out["logits"], "representations": out["representations"], "contacts": fused},
+                       toks, lengths, L)
+    nonpad = toks.ne(1)
+    report = {}
+    for b in range(toks.shape[0]):
+        e_max, e_l2 = rel(got["repr"][b], fix["repr"][b]), rel_l2(got["repr"][b], fix["repr"][b])
+        perr, zerr, zrel = contact_report(got["contacts"][b], fix["contacts"][b])
+        fperr = (fz["contacts"][b].cpu() - got["contacts"][b].cpu()).abs().max().item()
+        report[b] = dict(repr_rel_max=e_max, repr_rel_l2=e_l2, contact_prob=perr, contact_logit=zerr,
+                         contact_logit_rel=zrel, fused_vs_materialised=fperr)
+    raw, decided_ok, lerr = argmax_check(out["logits"].float().cpu(), fix["logits"], nonpad)
+    print(f"\n{name}: {report}; logits abs err {lerr:.2e}, argmax raw {raw:.4f}, decided ok {decided_ok}")
+    for b, r in report.items():
+        assert r["repr_rel_l2"] < 1e-3, (b, r)          # the contract in the L2 sense
+        assert r["repr_rel_max"] < 1.5e-3, (b, r)       # worst single element of 36 fp16-operand layers
+        assert r["contact_logit_rel"] < 3e-3 and r["contact_prob"] < 1e-2, (b, r)
+        assert r["fused_vs_materialised"] < 1e-4, (b, r)
+    assert decided_ok and raw > 0.98
+
+
+@pytest.mark.gpu
+def test_config3_3b_contacts_T258(model_3b):
+    _check_3b(model_3b, "esm2_3b_T258")
+
+
+@pytest.mark.gpu
+def test_config3_3b_contacts_padded_1022_300(model_3b):
+    _check_3b(model_3b, "esm2_3b_padded")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# config 5: MSA Transformer, 12 x 768, one 128 x 513 MSA
+# ------------------------------------------------------------------------------------------------------------
+def _msa_compare(got, fix, tag):
+    r = {}
+    r["repr_row0_max"], r["repr_row0_l2"] = rel(got["repr_row0"], fix["repr_row0"]), rel_l2(got["repr_row0"], fix["repr_row0"])
+    r["repr_sub_max"], r["repr_sub_l2"] = rel(got["repr_sub"], fix["repr_sub"]), rel_l2(got["repr_sub"], fix["repr_sub"])
+    r["logits_row0"] = rel(got["logits_row0"], fix["logits_row0"])
+    lerr = (got["logits_row0"].cpu() - fix["logits_row0"]).abs().max().item()
+    same = got["logits_argmax"].cpu() == fix["logits_argmax"]
+    decided = fix["logits_margin"].float() > 4 * lerr  # row-0 error as the scale, doubled
+    r["argmax_raw"], r["argmax_decided_ok"] = same.float().mean().item(), bool(same[decided].all())
+    r["contacts_prob"], r["contacts_logit"], r["contacts_logit_rel"] = contact_report(got["contacts"], fix["contacts"])
+    r["row_maps"] = max((got["row_maps"][k].cpu() - v).abs().max().item() for k, v in fix["row_maps"].items())
+    r["row_proj"] = (got["row_proj"].cpu() - fix["row_proj"]).abs().max().item()
+    r["row_max"] = (got["row_max"].cpu() - fix["row_max"]).abs().max().item()
+    # error of the deepest layer's maps vs the first layer's: the depth dependence VERDICT r1 asked about
+    L = fix["row_proj"].shape[0]
+    r["row_proj_first_last"] = ((got["row_proj"][0].cpu() - fix["row_proj"][0]).abs().max().item(),
+                                (got["row_proj"][L - 1].cpu() - fix["row_proj"][L - 1]).abs().max().item())
+    if "col_maps" in got and "col_maps" in fix:
+        r["col_maps"] = max((got["col_maps"][k].cpu() - v).abs().max().item() for k, v in fix["col_maps"].items())
+        r["col_proj"] = (got["col_proj"].cpu() - fix["col_proj"]).abs().max().item()
+    print(f"\nconfig 5 ({tag}): {r}")
+    return r
+
+
+def _msa_model_and_tokens(fix):
+    import argparse
+
+    import esm
+    from esm_amd.synth import synth_msa_state_dict
+
+    d = fix["dims"]
+    sd = synth_msa_state_dict(d["L"], d["E"], d["H"], d["F"], seed=d["seed"])
+    chk = GEN.checksum(sd)
+    assert abs(chk - fix["weights_checksum"]) < 1e-6 * abs(chk), "synthetic weight generator drifted"
+    ns = argparse.Namespace(layers=d["L"], embed_dim=d["E"], ffn_embed_dim=d["F"], attention_heads=d["H"], dropout=0.1,
+                            attention_dropout=0.1, activation_dropout=0.1, max_positions=1024, embed_positions_msa=True,
+                            embed_positions_msa_dim=d["E"], max_tokens=2 ** 14, max_tokens_per_msa=2 ** 14)
+    model = esm.MSATransformer(ns, esm.Alphabet.from_architecture("msa_transformer")).eval()
+    model.load_state_dict(sd)
+    return model, sd, fix["tokens"].to(torch.int64)
+
+
+@pytest.mark.gpu
+def test_config5_msa_full_size_against_reference_fixture():
+    fix = fixture("msa1b_config5")
+    L = fix["dims"]["L"]
+    model, _, toks = _msa_model_and_tokens(fix)
+    model = model.cuda()
+    with torch.no_grad():
+        out = model(toks.cuda(), repr_layers=[L], return_contacts=True)  # row + column attentions, 4.8 GB
+    got = GEN.slim_msa(out, L)
+    r = _msa_compare(got, fix, "HIP engine vs reference fixture")
+    assert r["repr_row0_l2"] < 1e-3 and r["repr_sub_l2"] < 1e-3, r
+    assert r["repr_row0_max"] < 2e-3 and r["repr_sub_max"] < 2e-3, r
+    assert r["logits_row0"] < 2e-3 and r["argmax_decided_ok"] and r["argmax_raw"] > 0.98, r
+    assert r["row_maps"] < 6e-3 and r["row_max"] < 6e-3, r        # tied scores: R * 64 fp16 products each
+    assert r["col_maps"] < 2e-3, r
+    assert r["contacts_prob"] < 1e-2 and r["contacts_logit_rel"] < 5e-3, r
+
+
+# ------------------------------------------------------------------------------------------------------------
+# CPU: the oracle against the same full-size fixtures
+# ------------------------------------------------------------------------------------------------------------
+def test_msa_oracle_matches_full_size_reference_fixture():
+    from oracle.msa_oracle import msa_forward
+
+    fix = fixture("msa1b_config5")
+    L, H = fix["dims"]["L"], fix["dims"]["H"]
+    _, sd, toks = _msa_model_and_tokens(fix)
+    with torch.no_grad():
+        out = msa_forward(sd, toks, L, H, repr_layers=[L], return_contacts=True)
+    got = GEN.slim_msa(out, L)
+    r = _msa_compare(got, fix, "oracle vs reference fixture")
+    assert r["repr_row0_max"] < 2e-5 and r["repr_sub_max"] < 2e-5 and r["logits_row0"] < 2e-5, r
+    # the reference sums the tied scores over row chunks (max_tokens_per_msa, axial_attention.py:40-73): fp32
+    # summation order differs from the oracle's single einsum, visible at 1e-4 on the sharpest maps of layer 12
+    assert r["row_maps"] < 3e-4 and r["col_maps"] < 3e-5 and r["contacts_prob"] < 1e-4, r
+    assert r["row_proj"] < 1e-3 and r["col_proj"] < 1e-3, r
+
+
+@pytest.mark.skipif(os.environ.get("ESM_AMD_SLOW_TESTS") != "1", reason="3B oracle: ~36 GB and minutes (ESM_AMD_SLOW_TESTS=1)")
+def test_esm2_oracle_matches_3b_reference_fixture():
+    from esm_amd.synth import synth_esm2_state_dict
+    from oracle.esm2_oracle import esm2_forward
+
+    fix = fixture("esm2_3b_T258")
+    d = fix["dims"]
+    sd = synth_esm2_state_dict(d["L"], d["E"], d["H"], seed=d["seed"])
+    toks = fix["tokens"].to(torch.int64)
+    with torch.no_grad():
+        out = esm2_forward(sd, toks, d["L"], d["H"], repr_layers=[d["L"]], return_contacts=True)
+    got = GEN.slim_esm2(out, toks, fix["lengths"], d["L"])
+    assert rel(got["repr"][0], fix["repr"][0]) < 2e-5
+    assert (got["contacts"][0] - fix["contacts"][0]).abs().max().item() < 2e-5
+    assert rel(got["logits"], fix["logits"]) < 2e-5
