@@ -7,10 +7,16 @@
 // epilogue in gemm.hip as [B,H,T,64]; v comes TRANSPOSED as vt[B,H,64,Tp] with the key index
 // permuted inside groups of 16 (4-groups 1 and 2 swapped).
 //
+// SCORE DOMAIN: q arrives scaled by d^-1/2 * log2(e) (the QKV epilogue folds it into the q scale), so q.k is
+// the score in the log2 domain and every softmax here is exp2; the saved row log-sum-exp `lse` is log2-domain
+// too (attn_probs_kernel, contacts.hip: p = exp2(q.k - lse)).  The masked_fill constant of the MSA column
+// attention (-10000, axial_attention.py:211-215) is scaled accordingly.
+//
 // attn_fwd_kernel: one workgroup = 4 waves = 128 query rows of one (batch, head); each wave
 // owns 32 query rows.  K / V^T tiles of 64 keys are staged HBM->LDS by global_load_lds_dwordx4
-// (double buffered; a three-buffer variant with a counted vmcnt exists as template STAGES=3 and measured
-// 6 % slower; 128-byte rows, 16-byte chunks XOR-swizzled with (row>>1)&7 on the source address and on
+// (double buffered; a three-buffer variant with a counted vmcnt measured 6 % slower in round 1 and was removed
+// together with the 64-rows-per-wave, 4-waves-per-SIMD and packed-fp32 variants — numbers in DESIGN.md §4.2;
+// 128-byte rows, 16-byte chunks XOR-swizzled with (row>>1)&7 on the source address and on
 // the read, so every ds_read_b128 is bank-conflict free).
 // The 1-D grid is mapped so that all query blocks of one (batch, head) run on ONE XCD (workgroup id
 // % 8): its K / V^T (2 x T x 128 B) is fetched into that XCD's L2 once instead of once per XCD
@@ -22,8 +28,8 @@
 //   the V^T A-operand uses the same (permuted) key order, so P goes registers -> MFMA with no
 //   LDS round trip and no lane permutation; O^T keeps the query in the lane (l&31) so the
 //   online-softmax rescale is a lane-local multiply.
-// Softmax is fp32 (exp2 with log2(e) folded in), P is rounded to the operand dtype for the PV
-// MFMA, accumulation is fp32.
+// Softmax is fp32 (exp2; see LAZY below), P is rounded to the operand dtype for the PV MFMA,
+// accumulation is fp32.
 //
 // attn_probs_kernel: re-computes S tile by tile from q, k and the saved log-sum-exp and writes
 // normalised fp32 probabilities for need_head_weights=True / the contact head
@@ -32,12 +38,13 @@
 #include "kernels.h"
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace esmk {
 
 constexpr float LOG2E = 1.4426950408889634f;
-// measured end to end in one run (profiles/r1_v6_attention_variants.log): variant 0 16.39 ms/step,
-// 1 (XCD-grouped grid) 16.14, 2 (three stages) 17.45, 4 (split reductions) 16.64, 7 (all) 17.44
+// round 1, end to end in one run (profiles/r1_v6_attention_variants.log): row-major grid 16.39 ms/step,
+// XCD-grouped grid 16.14 (kept), three LDS stages 17.45, split reductions 16.64 (both removed)
 constexpr int ATTN_DEFAULT_VARIANT = 1;
 constexpr int A_TILE = 64 * 128;  // bytes of one K (or V^T) tile: 64 rows x 128 B
 constexpr int A_STAGE = 2 * A_TILE + 256;  // K + V^T + 64 fp32 key-bias values
@@ -49,15 +56,27 @@ ESMK_DEV void attn_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// STAGES: LDS buffers of the K / V^T stream (2: one tile in flight, drained every tile; 3: two tiles in
-// flight behind a counted vmcnt).  TREE: 4-way split max / sum reductions.  xcdmap: see the file header.
-template <typename T, int STAGES, int TREE, int MINW = 2>
-__global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(
+// LAZY = 0: textbook online softmax (running maximum updated and O^T rescaled on every key tile).
+// LAZY = 1 (default): the exponent offset m_off is only moved when it has to be.  Scores arrive in the log2
+// domain (the QKV epilogue folds log2(e) into the q scale), and -m_off rides into the accumulator as the C operand
+// of the first QK^T MFMA of each 32-key tile, so a score leaves the matrix pipe as s - m_off and the probability is
+// ONE v_exp_f32 away: no per-score subtract, no per-tile maximum, no rescale of O^T.  After the exponentials, a
+// lane's partial row sum tells whether any of its scores ran more than ~12 octaves above the offset (sum > 4096,
+// inf or NaN): only then — and on every tile until each row of the wave has seen a finite score — the wave takes
+// the exact path (maximum, shift of the offset, rescale), which recomputes this tile's probabilities from the
+// untouched score registers.  Mathematically the same softmax; P <= 4096 stays far inside fp16 / bf16 range and
+// the row sum and O^T accumulate in fp32.  Per score the VALU work drops from max + fma + exp + add + cvt +
+// rescale (~7 issue slots, the pole of this kernel at head_dim 64: profiles/r1_v20_attention_pmc.txt) to
+// exp + add + cvt (~4).
+constexpr float LAZY_LIMIT = 4096.f;
+
+template <typename T, int LAZY>
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
     const float* __restrict__ key_bias, const int* __restrict__ seq_info, T* __restrict__ ctx,
     float* __restrict__ lse, int H, int BH, int nq, int Tlen, int Tp, int xcdmap, int fill_mode,
     const int* __restrict__ any_pad, AttnSegs segs) {
-    __shared__ __attribute__((aligned(16))) char smem[STAGES * A_STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[2 * A_STAGE];
     using V8 = typename Op<T>::v8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,27 +146,20 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qp + 16 * ks);
     }
 
-    // staging sources (2 rounds of 256 lanes each for K and for V^T)
-    const T* gk[2];
-    const T* gv[2];
-    int krow[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pos = j * 256 + tid;
-        const int r = pos >> 3, s = pos & 7;
-        const int c = s ^ ((r >> 1) & 7);
-        krow[j] = r;
-        gk[j] = kb + c * 8;                      // + key row * 64 (clamped per tile)
-        gv[j] = vb + (size_t)r * Tp + c * 8;     // + tile key offset
-    }
+    // staging sources: 2 rounds of 256 lanes each for K and for V^T.  Lane tid copies 16-byte chunk c of row
+    // r0 (round 0) and of row r0 + 32 (round 1): the swizzle (r >> 1) & 7 is the same for both rows, so one
+    // 32-bit element offset per stream is all that is kept in registers.
+    const int r0 = tid >> 3;
+    const int kcol = ((tid & 7) ^ ((r0 >> 1) & 7)) * 8;  // element offset of the chunk inside a 64-element row
+    const int voff = r0 * Tp + kcol;                      // V^T: row r0 (a dv), chunk c of the tile's 64 keys
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * A_STAGE;
         const int k0 = kt * 64;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int kr = min(k0 + krow[j], Tseg - 1);
-            glds16(gk[j] + (size_t)kr * 64, base + (j * 256 + wave * 64) * 16);
-            glds16(gv[j] + k0, base + A_TILE + (j * 256 + wave * 64) * 16);
+            const int kr = min(k0 + r0 + 32 * j, Tseg - 1);
+            glds16(kb + (size_t)kr * 64 + kcol, base + (j * 256 + wave * 64) * 16);
+            glds16(vb + (size_t)(voff + 32 * j * Tp) + k0, base + A_TILE + (j * 256 + wave * 64) * 16);
         }
         if (use_mask && tid < 64) {
             const int key = k0 + tid;
@@ -172,50 +184,51 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m2 = -INFINITY;  // running max in the log2 domain (score * log2 e)
-    float lsum = 0.f;      // this lane's share of the running denominator
+    // Scores are in the log2 domain.  m_off: the offset the probabilities of this row are currently expressed
+    // against (finite; LAZY = 0 keeps it at the running maximum); m_ok: the row has seen a finite score.
+    float m_off = 0.f;
+    bool m_ok = false;
+    float lsum = 0.f;  // this lane's share of the running denominator
+    f32x16 negm;       // -m_off in every slot: C operand of the first MFMA of a score tile (LAZY)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
 
-    // prologue: tile 0 (and 1) in flight
     if (ntiles > 0) stage(0, 0);
-    if constexpr (STAGES == 3) {
-        if (ntiles > 1) stage(1, 1);
-    } else {
-        wait_vmcnt0();
-        __syncthreads();
-    }
+    wait_vmcnt0();
+    __syncthreads();
 
     int cur = 0;
     for (int kt = 0; kt < ntiles; ++kt) {
         const char* sk = smem + cur * A_STAGE;
-        if constexpr (STAGES == 3) {
-            // tile kt has landed (tile kt+1 may stay in flight); the barrier also tells every wave that
-            // buffer (kt+2)%3 == (kt-1)%3 is no longer read, so tile kt+2 can be staged into it
-            if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            attn_barrier();
-            if (kt + 2 < ntiles) stage(cur == 0 ? 2 : cur - 1, kt + 2);
-            cur = (cur == 2) ? 0 : cur + 1;
-        } else {
-            if (kt + 1 < ntiles) stage(cur ^ 1, kt + 1);
-            cur ^= 1;
-        }
+        if (kt + 1 < ntiles) stage(cur ^ 1, kt + 1);
+        cur ^= 1;
         const char* sv = sk + A_TILE;
         const float* sb = reinterpret_cast<const float*>(sk + 2 * A_TILE);
 
-        // ---- S^T = K . Q^T for 64 keys (two 32-key tiles) ---------------------------------
+        // ---- S^T = K . Q^T (- m_off) for 64 keys (two 32-key tiles) ---------------------------
         f32x16 st[2];
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
+            if constexpr (LAZY) {
+                st[t2] = Op<T>::mma_keep_c(*reinterpret_cast<const V8*>(sk + t2 * 4096 + lrow + xo[0]), qf[0], negm);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[t2][r] = 0.f;
+                for (int ks = 1; ks < 4; ++ks) {
+                    const V8 kf = *reinterpret_cast<const V8*>(sk + t2 * 4096 + lrow + xo[ks]);
+                    st[t2] = Op<T>::mma(kf, qf[ks], st[t2]);
+                }
+            } else {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const V8 kf = *reinterpret_cast<const V8*>(sk + t2 * 4096 + lrow + xo[ks]);
-                st[t2] = Op<T>::mma(kf, qf[ks], st[t2]);
+                for (int r = 0; r < 16; ++r) st[t2][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const V8 kf = *reinterpret_cast<const V8*>(sk + t2 * 4096 + lrow + xo[ks]);
+                    st[t2] = Op<T>::mma(kf, qf[ks], st[t2]);
+                }
             }
         }
         // ---- key padding / tail mask (multihead_attention.py:368-374) -----------------------
         if (use_mask) {
+            const float fillv = -10000.f * LOG2E - (LAZY ? m_off : 0.f);  // masked_fill(-10000), same domain as st
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -223,84 +236,74 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(sb + t2 * 32 + 8 * g + 4 * h);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        st[t2][4 * g + e] = (bv[e] == INFINITY) ? -10000.f : st[t2][4 * g + e] + bv[e];
+                        st[t2][4 * g + e] = (bv[e] == INFINITY) ? fillv : st[t2][4 * g + e] + bv[e];
                 }
         }
-        // ---- online softmax (fp32) ---------------------------------------------------------
-        float mx;
-        if constexpr (TREE == 1) {
-            float mx4[4];  // four independent chains instead of one 32-deep dependency chain
+        // ---- softmax numerators (fp32) -----------------------------------------------------
+        V8 pf[4];
+        bool exact = true;
+        if constexpr (LAZY) {
+            // wave uniform: every row has a finite offset -> try the tile without touching the offset
+            if (__builtin_amdgcn_ballot_w64(!m_ok) == 0) {
+                // one dependent chain of plain v_add_f32: two chains get SLP-packed into v_pk_add_f32, which costs
+                // more issue time next to MFMAs than the two adds it replaces (MI355X_MICROARCH.md, price list)
+                float ps = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) mx4[c] = st[c >> 1][8 * (c & 1)];
+                for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+                    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int r = 1; r < 8; ++r) mx4[c] = fmaxf(mx4[c], st[c >> 1][8 * (c & 1) + r]);
-            mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
-        } else {
-            mx = st[0][0];
+                        for (int e = 0; e < 8; ++e) {
+                            const float p = __builtin_amdgcn_exp2f(st[t2][8 * ks + e]);
+                            ps += p;
+                            pf[2 * t2 + ks][e] = Op<T>::from(p);
+                        }
+                exact = __builtin_amdgcn_ballot_w64(!(ps <= LAZY_LIMIT)) != 0;  // also catches inf / NaN
+                if (!exact) lsum += ps;
+            }
+        }
+        if (exact) {
+            // maximum of this tile's (offset) scores over the row: 32 in this lane, 32 in lane ^ 32
+            float mx = st[0][0];
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t2][r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m2, mx * LOG2E);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        V8 pf[4];
-        if constexpr (TREE == 2) {
-            // (a) fp32 VALU instructions take 4 cycles per wave on gfx950 and the PMC pass of this kernel shows the
-            // VALU, not the matrix pipe, as the busier unit (profiles/r1_v20_attention_pmc.txt): the per-score fma and
-            // the row-sum adds are written on float pairs (v_pk_fma_f32 / v_pk_add_f32: two values per 4 cycles).
-            // (b) the running maximum rarely moves after the first key tiles: when no lane's maximum grew, alpha is
-            // exactly 1 and the rescale of O^T and of the denominator is skipped — bit-identical to multiplying by 1.
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            if (__builtin_amdgcn_ballot_w64(m_new != m2) != 0) {  // wave uniform
-                const float alpha = __builtin_amdgcn_exp2f(m2 - m_use);
-                lsum *= alpha;
-#pragma unroll
-                for (int d = 0; d < 2; ++d)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            // shift of the offset: up to the new maximum; the first finite tile of a row sets it outright
+            float delta, alpha;
+            if constexpr (LAZY) {
+                delta = m_ok ? fmaxf(mx, 0.f) : (mx == -INFINITY ? 0.f : mx);
+                alpha = m_ok ? __builtin_amdgcn_exp2f(-delta) : 1.f;  // nothing accumulated yet: O^T = 0, lsum = 0
+            } else {
+                // st holds raw scores: the offset becomes the running maximum itself
+                const float m_new = m_ok ? fmaxf(m_off, mx) : (mx == -INFINITY ? 0.f : mx);
+                delta = m_new;  // subtracted from the raw scores below
+                alpha = m_ok ? __builtin_amdgcn_exp2f(m_off - m_new) : 1.f;
+                m_off = m_new;
             }
-            m2 = m_new;
-            const f32x2 l2e = f32x2{LOG2E, LOG2E}, nm = f32x2{-m_use, -m_use};
-            f32x2 ps2 = f32x2{0.f, 0.f};
+            m_ok = m_ok || (mx != -INFINITY);
+            float ps = 0.f;
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        const f32x2 t = __builtin_elementwise_fma(
-                            f32x2{st[t2][8 * ks + e], st[t2][8 * ks + e + 1]}, l2e, nm);
-                        const f32x2 p = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                        ps2 += p;
-                        pf[2 * t2 + ks][e] = Op<T>::from(p[0]);
-                        pf[2 * t2 + ks][e + 1] = Op<T>::from(p[1]);
+                    for (int e = 0; e < 8; ++e) {
+                        const float p = __builtin_amdgcn_exp2f(st[t2][8 * ks + e] - delta);
+                        ps += p;
+                        pf[2 * t2 + ks][e] = Op<T>::from(p);
                     }
-                }
-            lsum += ps2[0] + ps2[1];
-        } else {
-        const float alpha = __builtin_amdgcn_exp2f(m2 - m_use);
-        m2 = m_new;
-        float ps4[4] = {0.f, 0.f, 0.f, 0.f};
+            lsum = lsum * alpha + ps;
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
+            for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            if constexpr (LAZY) {
+                m_off += delta;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float p = __builtin_amdgcn_exp2f(st[t2][8 * ks + e] * LOG2E - m_use);
-                    ps4[TREE ? 2 * t2 + ks : 0] += p;
-                    pf[2 * t2 + ks][e] = Op<T>::from(p);
-                }
+                for (int r = 0; r < 16; ++r) negm[r] = -m_off;
             }
-        lsum = lsum * alpha + ((ps4[0] + ps4[1]) + (ps4[2] + ps4[3]));
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
         }
         // ---- O^T += V^T . P^T ----------------------------------------------------------------
 #pragma unroll
@@ -310,12 +313,9 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(
                 const V8 vf = *reinterpret_cast<const V8*>(sv + d * 4096 + lrow + xo[kk]);
                 o[d] = Op<T>::mma(vf, pf[kk], o[d]);
             }
-        if constexpr (STAGES == 2) {
-            wait_vmcnt0();
-            __syncthreads();
-        }
+        wait_vmcnt0();
+        __syncthreads();
     }
-    if constexpr (STAGES == 3) attn_barrier();  // every wave is done with the K / V^T buffers
 
     // ---- normalise and store ctx[b*T + q][head*64 + dv] ---------------------------------------
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
@@ -342,35 +342,44 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(
         const V8 v = *reinterpret_cast<const V8*>(wl + r * 128 + ((c ^ (r & 7)) << 4));
         if (q0 + r < Tseg) *reinterpret_cast<V8*>(dst + (size_t)(q0 + r) * ((size_t)H * 64) + c * 8) = v;
     }
+    // log-sum-exp of the row in the log2 domain (the map kernels compute exp2(s - lse2))
     const int qrow = q0 + lm;
-    if (lse != nullptr && h == 0 && qrow < Tseg)
-        lse[rbase + qrow] = m2 * (1.0f / LOG2E) + logf(ltot);
+    if (lse != nullptr && h == 0 && qrow < Tseg) lse[rbase + qrow] = m_off + log2f(ltot);
 }
 
+// ---------------------------------------------------------------------------------------------
+// attn_fwd_pipe_kernel: the same math as attn_fwd_kernel<LAZY = 1>, software-pipelined so that the matrix pipe
+// and the VALU of ONE wave work on different key tiles at the same time.  Iteration t issues, as independent
+// instruction streams of one basic block,
+//     QK^T of tile t+1 (8 MFMAs, into the other score registers)   — needs only K(t+1) and Q
+//     P.V   of tile t-1 (8 MFMAs, with the probabilities kept from the previous iteration)
+//     exp2 / row sum / fp16 packing of tile t (32 v_exp + 32 v_add + 16 v_cvt_pk)
+// i.e. 16 MFMAs (512 matrix-pipe cycles) next to ~450 cycles of VALU issue: two scores' worth of softmax (2 exp,
+// 2 add, 1 cvt_pk) fit beside each MFMA.  attn_fwd_kernel runs the three phases back to back in every wave and
+// relies on the other waves of the SIMD being out of phase; its PMC profile shows MFMA-busy + VALU-busy ~ 92 %,
+// i.e. hardly any overlap (profiles/r1_v20_attention_pmc.txt).
+// The lazy-offset bookkeeping is unchanged; when the exact path moves the offset in iteration t, the scores of
+// tile t+1 (already computed against the old offset) are shifted by the same amount.
+// LDS: K tiles double buffered (K(t+2) lands while QK^T(t+1) reads), V^T tiles in a ring of three (V(t-1) is read
+// while V(t+1) lands), key-bias rows in a ring of three: 2 x 8 + 3 x 8 KiB + 768 B.
+// ---------------------------------------------------------------------------------------------
+constexpr int PIPE_LDS = 2 * A_TILE + 3 * A_TILE + 3 * 256;
 
-// ---------------------------------------------------------------------------------------------
-// attn_fwd2_kernel: same algorithm, 64 query rows per wave (two independent 32-row blocks), 256 per
-// workgroup.  Every K / V^T fragment read from the LDS feeds two MFMAs, and the two blocks' softmax
-// chains are independent instruction streams inside one wave: while block 0's exponentials occupy the
-// VALU, block 1's MFMAs (and vice versa) keep the matrix pipe busy without relying on another workgroup
-// being in the complementary phase.  ~230 VGPRs -> 2 waves per SIMD.
-// ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(
+__global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
     const float* __restrict__ key_bias, const int* __restrict__ seq_info, T* __restrict__ ctx,
-    float* __restrict__ lse, int H, int BH, int nq, int Tlen, int Tp, int fill_mode,
-    const int* __restrict__ any_pad) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * A_STAGE];
+    float* __restrict__ lse, int H, int BH, int nq, int Tlen, int Tp, int xcdmap, int fill_mode,
+    const int* __restrict__ any_pad, AttnSegs segs) {
+    __shared__ __attribute__((aligned(16))) char smem[PIPE_LDS];
     using V8 = typename Op<T>::v8;
-    using V4 = typename Op<T>::v4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, lm = lane & 31;
     int bh, qblk;
     {
         const int id = blockIdx.x;
-        const int bh8 = BH & ~7;
+        const int bh8 = xcdmap ? (BH & ~7) : 0;
         if (id < bh8 * nq) {
             const int r = id >> 3;
             qblk = r % nq;
@@ -382,11 +391,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(
         }
     }
     const int b = bh / H, head = bh - b * H;
-    const int q0 = qblk * 256 + wave * 64;  // block 0: rows q0..q0+31, block 1: q0+32..q0+63
+    int row0 = 0, Tseg = Tlen, qrel = qblk * 128;
+    bool seg_pad = false;
+    if (segs.work != nullptr) {  // token-packed batch: see attn_fwd_kernel
+        row0 = __builtin_amdgcn_readfirstlane(segs.work[4 * qblk]);
+        Tseg = __builtin_amdgcn_readfirstlane(segs.work[4 * qblk + 1]);
+        qrel = __builtin_amdgcn_readfirstlane(segs.work[4 * qblk + 2]);
+        seg_pad = segs.npad[__builtin_amdgcn_readfirstlane(segs.work[4 * qblk + 3])] > 0;
+    }
+    const int q0 = qrel + wave * 32;
+    const size_t rbase = (size_t)bh * Tlen + row0;
 
-    int kv_end = Tlen;
-    bool use_mask = (Tlen & 63) != 0;
-    if (fill_mode) {
+    int kv_end = Tseg;
+    bool use_mask = (Tseg & 63) != 0;
+    if (segs.work != nullptr) {
+        if (seg_pad) use_mask = true;
+        else key_bias = nullptr;
+    } else if (fill_mode) {
         if (key_bias != nullptr && any_pad != nullptr && any_pad[0] != 0) use_mask = true;
         else key_bias = nullptr;
     } else if (key_bias != nullptr) {
@@ -400,176 +421,228 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(
         }
     }
     const int ntiles = (kv_end + 63) >> 6;
-    const T* kb = k + (size_t)bh * Tlen * 64;
-    const T* vb = vt + (size_t)bh * 64 * Tp;
 
-    V8 qf[2][4];
+    const T* kb = k + rbase * 64;
+    const T* vb = vt + (size_t)bh * 64 * Tp + row0;
+
+    V8 qf[4];
+    {
+        const int qr = min(q0 + lm, Tseg - 1);
+        const T* qp = q + (rbase + qr) * 64 + 8 * h;
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        const int qr = min(q0 + 32 * blk + lm, Tlen - 1);
-        const T* qp = q + ((size_t)bh * Tlen + qr) * 64 + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[blk][ks] = *reinterpret_cast<const V8*>(qp + 16 * ks);
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qp + 16 * ks);
     }
 
-    const T* gk[2];
-    const T* gv[2];
-    int krow[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pos = j * 256 + tid;
-        const int r = pos >> 3, sl = pos & 7;
-        const int c = sl ^ ((r >> 1) & 7);
-        krow[j] = r;
-        gk[j] = kb + c * 8;
-        gv[j] = vb + (size_t)r * Tp + c * 8;
-    }
-    auto stage = [&](int buf, int kt) {
-        char* base = smem + buf * A_STAGE;
+    char* const lds_k = smem;                    // 2 K tiles
+    char* const lds_v = smem + 2 * A_TILE;       // 3 V^T tiles
+    float* const lds_b = reinterpret_cast<float*>(smem + 5 * A_TILE);  // 3 key-bias rows of 64
+    const int r0 = tid >> 3;
+    const int kcol = ((tid & 7) ^ ((r0 >> 1) & 7)) * 8;
+    const int voff = r0 * Tp + kcol;
+    auto stage_k = [&](int kt) {  // K tile kt and its key-bias row
+        char* base = lds_k + (kt & 1) * A_TILE;
         const int k0 = kt * 64;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int kr = min(k0 + krow[j], Tlen - 1);
-            glds16(gk[j] + (size_t)kr * 64, base + (j * 256 + wave * 64) * 16);
-            glds16(gv[j] + k0, base + A_TILE + (j * 256 + wave * 64) * 16);
+            const int kr = min(k0 + r0 + 32 * j, Tseg - 1);
+            glds16(kb + (size_t)kr * 64 + kcol, base + (j * 256 + wave * 64) * 16);
         }
         if (use_mask && tid < 64) {
             const int key = k0 + tid;
             float bv = -INFINITY;
-            if (key < Tlen) {
-                bv = key_bias ? key_bias[(size_t)b * Tlen + key] : 0.f;
+            if (key < Tseg) {
+                bv = key_bias ? key_bias[(size_t)b * Tlen + row0 + key] : 0.f;
                 if (fill_mode) bv = (bv != 0.f) ? INFINITY : 0.f;
             }
-            reinterpret_cast<float*>(base + 2 * A_TILE)[tid] = bv;
+            lds_b[(kt % 3) * 64 + tid] = bv;
         }
+    };
+    auto stage_v = [&](int kt) {
+        char* base = lds_v + (kt % 3) * A_TILE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            glds16(vb + (size_t)(voff + 32 * j * Tp) + kt * 64, base + (j * 256 + wave * 64) * 16);
     };
 
     const int lrow = lm * 128;
     const int swz = (lane >> 1) & 7;
     int xo[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) xo[c] = ((2 * c + h) ^ swz) << 4;
+    for (int c = 0; c < 4; ++c) xo[c] = lrow + (((2 * c + h) ^ swz) << 4);
 
-    f32x16 o[2][2];
-    float m2[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+    f32x16 o[2];
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_off = 0.f, lsum = 0.f;
+    bool m_ok = false;
+    f32x16 negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+
+    // scores of one 64-key tile against the current offset: st = K . Q^T - m_off
+    auto qk_tile = [&](int kt, f32x16 (&st)[2]) {
+        const char* sk = lds_k + (kt & 1) * A_TILE;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            st[t2] = Op<T>::mma_keep_c(*reinterpret_cast<const V8*>(sk + t2 * 4096 + xo[0]), qf[0], negm);
+#pragma unroll
+            for (int ks = 1; ks < 4; ++ks)
+                st[t2] = Op<T>::mma(*reinterpret_cast<const V8*>(sk + t2 * 4096 + xo[ks]), qf[ks], st[t2]);
+        }
+    };
+    auto pv_tile = [&](int kt, const V8 (&pf)[4]) {
+        const char* sv = lds_v + (kt % 3) * A_TILE;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[blk][d][r] = 0.f;
+            for (int kk = 0; kk < 4; ++kk)
+                o[d] = Op<T>::mma(*reinterpret_cast<const V8*>(sv + d * 4096 + xo[kk]), pf[kk], o[d]);
+    };
 
-    if (ntiles > 0) stage(0, 0);
-    wait_vmcnt0();
-    __syncthreads();
-
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < ntiles) stage(cur ^ 1, kt + 1);
-        const char* sk = smem + cur * A_STAGE;
-        const char* sv = sk + A_TILE;
-        const float* sb = reinterpret_cast<const float*>(sk + 2 * A_TILE);
-
-        // ---- S^T = K . Q^T: every K fragment serves both query blocks ---------------------------------
-        f32x16 st[2][2];
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[blk][t2][r] = 0.f;
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const V8 kf = *reinterpret_cast<const V8*>(sk + t2 * 4096 + lrow + xo[ks]);
-                st[0][t2] = Op<T>::mma(kf, qf[0][ks], st[0][t2]);
-                st[1][t2] = Op<T>::mma(kf, qf[1][ks], st[1][t2]);
-            }
+    // one iteration: scores of tile kt are in `sc`; its probabilities go to `pc`; `sn` receives the scores of
+    // tile kt+1 (unless LAST) and `pp` holds the probabilities of tile kt-1 (zeros for kt = 0, multiplied into the
+    // zeroed ring slot 2).  No branch between the MFMAs and the exponentials: one basic block for the scheduler.
+    auto body = [&](auto last_tag, int kt, f32x16 (&sc)[2], f32x16 (&sn)[2], V8 (&pc)[4], const V8 (&pp)[4]) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        if (kt + 2 < ntiles) stage_k(kt + 2);
+        if (kt + 1 < ntiles) stage_v(kt + 1);
         if (use_mask) {
+            const float* sb = lds_b + (kt % 3) * 64;
+            const float fillv = -10000.f * LOG2E - m_off;
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(sb + t2 * 32 + 8 * g + 4 * h);
 #pragma unroll
-                    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            st[blk][t2][4 * g + e] = (bv[e] == INFINITY) ? -10000.f : st[blk][t2][4 * g + e] + bv[e];
+                    for (int e = 0; e < 4; ++e)
+                        sc[t2][4 * g + e] = (bv[e] == INFINITY) ? fillv : sc[t2][4 * g + e] + bv[e];
                 }
         }
-        // ---- online softmax, two independent chains ---------------------------------------------------------
-        V8 pf[2][4];
+        // ---- the pipelined block: three independent streams -------------------------------------------
+        if constexpr (!LAST) qk_tile(kt + 1, sn);
+        pv_tile(kt + 2, pp);  // ring slot (kt + 2) % 3 == (kt - 1) % 3
+        float ps = 0.f;
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            float mx = st[blk][0][0];
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float p = __builtin_amdgcn_exp2f(sc[t2][8 * ks + e]);
+                    ps += p;
+                    pc[2 * t2 + ks][e] = Op<T>::from(p);
+                }
+        // fast path valid only if every row already has a finite offset and nothing ran away from it
+        const bool exact = __builtin_amdgcn_ballot_w64(!m_ok || !(ps <= LAZY_LIMIT)) != 0;
+        if (!exact) {
+            lsum += ps;
+        } else {
+            float mx = sc[0][0];
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[blk][t2][r]);
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[t2][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m2[blk], mx * LOG2E);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m2[blk] - m_use);
-            m2[blk] = m_new;
-            float ps = 0.f;
+            const float delta = m_ok ? fmaxf(mx, 0.f) : (mx == -INFINITY ? 0.f : mx);
+            const float alpha = m_ok ? __builtin_amdgcn_exp2f(-delta) : 1.f;
+            m_ok = m_ok || (mx != -INFINITY);
+            float pse = 0.f;
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float pv = __builtin_amdgcn_exp2f(st[blk][t2][8 * ks + e] * LOG2E - m_use);
-                        ps += pv;
-                        pf[blk][2 * t2 + ks][e] = Op<T>::from(pv);
+                        const float p = __builtin_amdgcn_exp2f(sc[t2][8 * ks + e] - delta);
+                        pse += p;
+                        pc[2 * t2 + ks][e] = Op<T>::from(p);
                     }
-            lsum[blk] = lsum[blk] * alpha + ps;
+            lsum = lsum * alpha + pse;
+            // O^T already holds tile kt-1 (program order): everything accumulated so far is relative to the old offset
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[blk][d][r] *= alpha;
-        }
-        // ---- O^T += V^T . P^T: every V^T fragment serves both query blocks ---------------------------------
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            if constexpr (!LAST) {  // the scores of tile kt+1 were computed against the old offset
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+                for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const V8 vf = *reinterpret_cast<const V8*>(sv + d * 4096 + lrow + xo[kk]);
-                o[0][d] = Op<T>::mma(vf, pf[0][kk], o[0][d]);
-                o[1][d] = Op<T>::mma(vf, pf[1][kk], o[1][d]);
+                    for (int r = 0; r < 16; ++r) sn[t2][r] -= delta;
             }
+            m_off += delta;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] = -m_off;
+        }
         wait_vmcnt0();
         __syncthreads();
-    }
+    };
 
-    // ---- normalise and store: [64 queries][64 dv] per wave through an 8 KiB LDS slice ----------------------
-    char* wl = smem + wave * 8192;
-    T* dst = ctx + ((size_t)b * Tlen) * ((size_t)H * 64) + head * 64;
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        const float ltot = lsum[blk] + __shfl_xor(lsum[blk], 32, 64);
-        const float inv = 1.0f / ltot;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                V4 pk;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = Op<T>::from(o[blk][d][4 * g + e] * inv);
-                *reinterpret_cast<V4*>(wl + (32 * blk + lm) * 128 + (((4 * d + g) ^ (lm & 7)) << 4) + 8 * h) = pk;
-            }
-        const int qrow = q0 + 32 * blk + lm;
-        if (lse != nullptr && h == 0 && qrow < Tlen)
-            lse[(size_t)bh * Tlen + qrow] = m2[blk] * (1.0f / LOG2E) + logf(ltot);
+    // prologue: K(0), K(1), V(0) resident, V ring slot 2 zeroed (tile "-1"); scores of tile 0
+    stage_k(0);
+    if (ntiles > 1) stage_k(1);
+    stage_v(0);
+    {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        reinterpret_cast<f32x4*>(lds_v + 2 * A_TILE)[tid] = z;
+        reinterpret_cast<f32x4*>(lds_v + 2 * A_TILE)[tid + 256] = z;
     }
+    wait_vmcnt0();
+    __syncthreads();
+    f32x16 sa[2], sb2[2];
+    V8 pa[4], pb[4];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            pa[i][e] = Op<T>::from(0.f);
+            pb[i][e] = Op<T>::from(0.f);
+        }
+    qk_tile(0, sa);
+    using NotLast = std::integral_constant<bool, false>;
+    using Last = std::integral_constant<bool, true>;
+    int kt = 0;
+    for (; kt + 2 < ntiles; kt += 2) {
+        body(NotLast(), kt, sa, sb2, pa, pb);
+        body(NotLast(), kt + 1, sb2, sa, pb, pa);
+    }
+    const bool two_left = kt + 2 == ntiles;  // wave uniform
+    if (two_left) {
+        body(NotLast(), kt, sa, sb2, pa, pb);
+        body(Last(), kt + 1, sb2, sa, pb, pa);
+    } else {
+        body(Last(), kt, sa, sb2, pa, pb);
+    }
+    // the last tile's P.V
+    if (two_left) pv_tile(ntiles - 1, pb);
+    else pv_tile(ntiles - 1, pa);
+    __syncthreads();  // every wave is done with the K / V^T buffers (the epilogue reuses the LDS)
+
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / ltot;
+    using V4 = typename Op<T>::v4;
+    char* wl = smem + wave * 4096;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            V4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = Op<T>::from(o[d][4 * g + e] * inv);
+            *reinterpret_cast<V4*>(wl + lm * 128 + (((4 * d + g) ^ (lm & 7)) << 4) + 8 * h) = pk;
+        }
+    T* dst = ctx + ((size_t)b * Tlen + row0) * ((size_t)H * 64) + head * 64;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
         const int pc = it * 64 + lane;
         const int r = pc >> 3, c = pc & 7;
         const V8 v = *reinterpret_cast<const V8*>(wl + r * 128 + ((c ^ (r & 7)) << 4));
-        if (q0 + r < Tlen) *reinterpret_cast<V8*>(dst + (size_t)(q0 + r) * ((size_t)H * 64) + c * 8) = v;
+        if (q0 + r < Tseg) *reinterpret_cast<V8*>(dst + (size_t)(q0 + r) * ((size_t)H * 64) + c * 8) = v;
     }
+    const int qrow = q0 + lm;
+    if (lse != nullptr && h == 0 && qrow < Tseg) lse[rbase + qrow] = m_off + log2f(ltot);
 }
 
 static hipError_t launch_attention_impl(const void* q, const void* k, const void* vt, const float* key_bias,
@@ -605,46 +678,28 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
     if (B <= 0 || H <= 0 || T <= 0 || Tp < T || (Tp & 63)) return hipErrorInvalidValue;
     const int nq = segs.work != nullptr ? n_items : (T + 127) / 128;
     dim3 grid(nq * B * H);
-    // ESMK_ATTN (read once): bit 0 XCD-grouped grid, bit 1 three LDS stages, bit 2 split reductions,
-    // bit 3 64 query rows per wave, bit 4 four waves per SIMD, bit 5 packed softmax + lazy rescale
+    // ESMK_ATTN (read once): bit 0 XCD-grouped grid (default on), bit 1 = textbook online softmax instead of the
+    // lazy-offset one, bit 2 = software-pipelined kernel (A/B measurements; all are exact softmax)
     static const int var = [] {
         const char* e = getenv("ESMK_ATTN");
         return e ? atoi(e) : ATTN_DEFAULT_VARIANT;
     }();
-#define ESMK_ATTN_LAUNCH(TT, ST, TR)                                                                    \
-    hipLaunchKernelGGL((attn_fwd_kernel<TT, ST, TR>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k, \
+#define ESMK_ATTN_LAUNCH(TT, LZ)                                                                      \
+    hipLaunchKernelGGL((attn_fwd_kernel<TT, LZ>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k,   \
                        (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad, segs)
-#define ESMK_ATTN_VARIANTS(TT)                                   \
-    if (var & 32) {  /* packed softmax arithmetic + rescale only when a maximum grew */ \
-        ESMK_ATTN_LAUNCH(TT, 2, 2);                              \
-    } else if (var & 16) {  /* <= 128 VGPRs: four waves per SIMD */     \
-        hipLaunchKernelGGL((attn_fwd_kernel<TT, 2, 0, 4>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k, \
-                           (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad, segs); \
-    } else                                                       \
-    switch ((var >> 1) & 3) {                                    \
-        case 0: ESMK_ATTN_LAUNCH(TT, 2, 0); break;               \
-        case 1: ESMK_ATTN_LAUNCH(TT, 3, 0); break;               \
-        case 2: ESMK_ATTN_LAUNCH(TT, 2, 1); break;               \
-        default: ESMK_ATTN_LAUNCH(TT, 3, 1); break;              \
-    }
-    if ((var & 8) && segs.work != nullptr) return hipErrorInvalidValue;  // the 64-rows-per-wave variant is dense only
-    if (var & 8) {  // 64 query rows per wave
-        const int nq2 = (T + 255) / 256;
-        dim3 grid2(nq2 * B * H);
-        if (operand_dtype == ESMK_DT_BF16)
-            hipLaunchKernelGGL((attn_fwd2_kernel<__bf16>), grid2, dim3(256), 0, st, (const __bf16*)q, (const __bf16*)k,
-                               (const __bf16*)vt, key_bias, seq_info, (__bf16*)ctx, lse, H, B * H, nq2, T, Tp, fill_mode,
-                               any_pad);
-        else
-            hipLaunchKernelGGL((attn_fwd2_kernel<_Float16>), grid2, dim3(256), 0, st, (const _Float16*)q,
-                               (const _Float16*)k, (const _Float16*)vt, key_bias, seq_info, (_Float16*)ctx, lse, H, B * H,
-                               nq2, T, Tp, fill_mode, any_pad);
-    } else if (operand_dtype == ESMK_DT_BF16) {
-        ESMK_ATTN_VARIANTS(__bf16)
+#define ESMK_ATTN_PIPE(TT)                                                                            \
+    hipLaunchKernelGGL((attn_fwd_pipe_kernel<TT>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k,  \
+                       (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad, segs)
+    if (operand_dtype == ESMK_DT_BF16) {
+        if (var & 4) ESMK_ATTN_PIPE(__bf16);
+        else if (var & 2) ESMK_ATTN_LAUNCH(__bf16, 0);
+        else ESMK_ATTN_LAUNCH(__bf16, 1);
     } else {
-        ESMK_ATTN_VARIANTS(_Float16)
+        if (var & 4) ESMK_ATTN_PIPE(_Float16);
+        else if (var & 2) ESMK_ATTN_LAUNCH(_Float16, 0);
+        else ESMK_ATTN_LAUNCH(_Float16, 1);
     }
-#undef ESMK_ATTN_VARIANTS
+#undef ESMK_ATTN_PIPE
 #undef ESMK_ATTN_LAUNCH
     return hipGetLastError();
 }
@@ -716,8 +771,8 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const T* __restrict__ q
             for (int r = 0; r < 16; ++r) {
                 const int qr = q0 + mfma32_row(r, h);
                 if (qr < Tlen) {
-                    const float sc = (fill && kb != 0.f) ? -10000.f : s[r] + kb;  // masked_fill vs additive -inf
-                    const float p = __expf(sc - row_lse[r]) * row_keep[r];
+                    const float sc = (fill && kb != 0.f) ? -10000.f * LOG2E : s[r] + kb;  // masked_fill vs additive -inf
+                    const float p = __builtin_amdgcn_exp2f(sc - row_lse[r]) * row_keep[r];  // log2 domain
                     out[(size_t)qr * Tlen + key] = (O)p;
                 }
             }

@@ -19,7 +19,6 @@
 namespace esmk {
 
 namespace {
-constexpr float LOG2E_ = 1.4426950408889634f;
 constexpr int HD = 128;
 constexpr int K_TILE = 64 * HD * 2;   // 16 KiB
 constexpr int V_TILE = HD * 128;      // 16 KiB
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t2][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m2, mx * LOG2E_);
+        const float m_new = fmaxf(m2, mx);  // scores are log2-domain (q carries log2 e, see attention.hip)
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m2 - m_use);
         m2 = m_new;
@@ -192,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float p = __builtin_amdgcn_exp2f(st[t2][8 * ks + e] * LOG2E_ - m_use);
+                    const float p = __builtin_amdgcn_exp2f(st[t2][8 * ks + e] - m_use);
                     ps += p;
                     pf[2 * t2 + ks][e] = Op<T>::from(p);
                 }
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd128_kernel(
         if (q0 + r < Tseg) *reinterpret_cast<V8*>(dst + (size_t)(q0 + r) * ((size_t)H * HD) + c * 8) = v;
     }
     const int qrow = q0 + lm;
-    if (lse != nullptr && h == 0 && qrow < Tseg) lse[rbase + qrow] = m2 * (1.0f / LOG2E_) + logf(ltot);
+    if (lse != nullptr && h == 0 && qrow < Tseg) lse[rbase + qrow] = m2 + log2f(ltot);  // log2 domain
 }
 
 template <typename TT>
@@ -325,7 +324,7 @@ __global__ __launch_bounds__(256) void attn_probs128_kernel(const T* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qr = q0 + mfma32_row(r, h);
-                if (qr < Tlen) out[(size_t)qr * Tlen + key] = (O)(__expf(s[r] + kbv - row_lse[r]) * row_keep[r]);
+                if (qr < Tlen) out[(size_t)qr * Tlen + key] = (O)(__builtin_amdgcn_exp2f(s[r] + kbv - row_lse[r]) * row_keep[r]);
             }
         }
     }

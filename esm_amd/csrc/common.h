@@ -25,6 +25,13 @@ struct Op<_Float16> {
     static ESMK_DEV f32x16 mma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
+    // D = A.B + C with D in registers of its own: C (e.g. a bias broadcast that is reused for every tile) stays
+    // intact.  The builtin lets the register allocator tie D to C and then copies C first (16 v_mov per tile).
+    static ESMK_DEV f32x16 mma_keep_c(v8 a, v8 b, const f32x16& c) {
+        f32x16 d;
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+        return d;
+    }
     static ESMK_DEV _Float16 from(float x) { return (_Float16)x; }
     static ESMK_DEV float to(_Float16 x) { return (float)x; }
 };
@@ -35,6 +42,11 @@ struct Op<__bf16> {
     using v4 = bf16x4;
     static ESMK_DEV f32x16 mma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static ESMK_DEV f32x16 mma_keep_c(v8 a, v8 b, const f32x16& c) {
+        f32x16 d;
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+        return d;
     }
     static ESMK_DEV __bf16 from(float x) { return (__bf16)x; }
     static ESMK_DEV float to(__bf16 x) { return (float)x; }

@@ -79,11 +79,10 @@ __global__ __launch_bounds__(256, HD == 128 ? 1 : 2) void contact_accum_kernel(
     const float* __restrict__ key_bias, const int64_t* __restrict__ tokens, const float* __restrict__ wreg,
     float* __restrict__ acc_out, float* __restrict__ rowp, float* __restrict__ colp, int B, int H, int Tlen,
     int layer, int G, int pad_idx, int eos_idx, int bos, int eos) {
-    // per wave and head of the group: lse * log2(e) of the 32 queries, 128 column sums, 2 x 32 row sums
+    // per wave and head of the group: lse (log2 domain, as q.k is: attention.hip) of the 32 queries, 128 column sums, 2 x 32 row sums
     extern __shared__ float s_dyn[];
     using V8 = typename Op<T>::v8;
     constexpr int KS = HD / 16;
-    constexpr float LOG2E = 1.4426950408889634f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hh = lane >> 5, lm = lane & 31;
     const int nQ = (Tlen + 127) >> 7;  // query blocks == key chunks
@@ -107,7 +106,7 @@ __global__ __launch_bounds__(256, HD == 128 ? 1 : 2) void contact_accum_kernel(
     for (int idx = lane; idx < (h1 - h0) * 32; idx += 64) {
         const int hd = h0 + (idx >> 5), qq = q0 + (idx & 31);
         const bool keep = qq < Tlen && residue_mask(tok, qq, Tlen, pad_idx, eos_idx, bos, eos) != 0.f;
-        s_lse[idx] = keep ? lse[((size_t)b * H + hd) * Tlen + qq] * LOG2E : __builtin_inff();
+        s_lse[idx] = keep ? lse[((size_t)b * H + hd) * Tlen + qq] : __builtin_inff();  // lse is log2-domain
     }
     float kb2[4];  // key bias in the exp2 domain: 0, or -inf for <pad> / masked / out-of-range keys
     int krow[4];
@@ -116,7 +115,7 @@ __global__ __launch_bounds__(256, HD == 128 ? 1 : 2) void contact_accum_kernel(
         const int key = kc + jj * 32 + lm;
         krow[jj] = min(key, Tlen - 1);
         const bool keep = key < Tlen && residue_mask(tok, key, Tlen, pad_idx, eos_idx, bos, eos) != 0.f;
-        kb2[jj] = keep ? (key_bias != nullptr ? key_bias[(size_t)b * Tlen + key] * LOG2E : 0.f) : -__builtin_inff();
+        kb2[jj] = keep ? (key_bias != nullptr ? key_bias[(size_t)b * Tlen + key] : 0.f) : -__builtin_inff();
     }
     const int qr = min(q0 + lm, Tlen - 1);
     const int nblk = min(4, (Tlen - kc + 31) >> 5);  // key blocks of this chunk that hold a key (wave uniform)
@@ -164,8 +163,8 @@ __global__ __launch_bounds__(256, HD == 128 ? 1 : 2) void contact_accum_kernel(
                 float cs = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    // exp(s + key_bias - lse); -inf + (-(+inf)) stays -inf -> 0
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, cr[r]) + kb2[jj]);
+                    // 2^(s + key_bias - lse) with log2-domain scores; -inf + (-(+inf)) stays -inf -> 0
+                    const float p = __builtin_amdgcn_exp2f(s[r] + cr[r] + kb2[jj]);
                     acc[jj][r] = __builtin_fmaf(wl, p, acc[jj][r]);
                     rs[r] += p;
                     cs += p;
@@ -231,7 +230,6 @@ __global__ __launch_bounds__(256, 2) void contact_accum64_kernel(
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     using V8 = typename Op<T>::v8;
     constexpr int PARK = 10, KBUF = 128 * 128;
-    constexpr float LOG2E = 1.4426950408889634f;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5, lm = lane & 31;
@@ -307,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void contact_accum64_kernel(
             for (int idx = lane; idx < (he - hs) * 32; idx += 64) {
                 // lane idx & 31 == lm for both halves: qkeep is the mask of query q0 + (idx & 31)
                 const int qq = min(q0 + (idx & 31), Tlen - 1);
-                const float v = lse[((size_t)b * H + hs + (idx >> 5)) * Tlen + qq] * LOG2E;
+                const float v = lse[((size_t)b * H + hs + (idx >> 5)) * Tlen + qq];  // log2 domain
                 s_lse[idx] = qkeep ? v : __builtin_inff();
             }
         }
@@ -326,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void contact_accum64_kernel(
                     rs[i] = f32x2{0.f, 0.f};
                 }
                 const float wl = wreg[layer * H + hd];
-                const f32x2 wl2 = f32x2{wl, wl}, l2e = f32x2{LOG2E, LOG2E};
+                const f32x2 wl2 = f32x2{wl, wl};
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     if (jj < nblk) {  // wave uniform
@@ -341,8 +339,8 @@ __global__ __launch_bounds__(256, 2) void contact_accum64_kernel(
                         f32x2 cs2 = f32x2{0.f, 0.f};
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
-                            // exp(s + key_bias - lse); -inf stays -inf -> 0
-                            const f32x2 t = __builtin_elementwise_fma(f32x2{s[2 * i], s[2 * i + 1]}, l2e, cr[i]);
+                            // 2^(s + key_bias - lse) with log2-domain scores; -inf stays -inf -> 0
+                            const f32x2 t = f32x2{s[2 * i], s[2 * i + 1]} + cr[i];
                             const f32x2 p = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
                             acc[jj][i] = __builtin_elementwise_fma(wl2, p, acc[jj][i]);
                             rs[i] += p;

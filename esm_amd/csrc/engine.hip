@@ -15,6 +15,8 @@
 using namespace esmk;
 using namespace esmk_host;
 
+static constexpr float kLog2e = 1.4426950408889634f;
+
 namespace {
 thread_local std::string g_err;
 }
@@ -658,7 +660,9 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         g.H = H;
         g.E = EA;
         g.Tp = w.Tp;
-        g.scaling = 1.0f / sqrtf((float)m->D);
+        // q carries d^-1/2 (multihead_attention.py:256-261) AND log2(e): the attention / map / contact kernels
+        // work on log2-domain scores (softmax as exp2, see attention.hip)
+        g.scaling = kLog2e / sqrtf((float)m->D);
         g.head_dim = m->D == 128 ? 128 : 64;
         g.row_pos = row_pos;
         if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;  // q, k: weight rows [0,2EA)

@@ -347,7 +347,8 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
             if (lnorm(x, o.col.lng, o.col.lnb, h, nullptr, ex)) return 1;
         }
         if (Rp != R) ESMK_TRY(hipMemsetAsync(vt, 0, (size_t)B * C * H * 64 * Rp * os, st));
-        if (qkv(o.col, R, Rp, 1.0f / sqrtf(64.0f), nullptr, 0)) return 1;
+        // log2(e) folded into the q scale: the flash / map kernels work on log2-domain scores (attention.hip)
+        if (qkv(o.col, R, Rp, 1.4426950408889634f / sqrtf(64.0f), nullptr, 0)) return 1;
         float* lse = want_col ? (float*)(ws + w.lse) : nullptr;
         {
             ProfScope ps(m, st, PC_MSA_COL_ATTN, 4.0 * N * (double)R * E, 4 * NE * os);

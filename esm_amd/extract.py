@@ -93,11 +93,12 @@ def gather_rows(local_rows: torch.Tensor, local_index: torch.Tensor, n_total: in
 
 
 def default_writer_threads() -> int:
-    """``torch.save`` of a 5 MB per-sequence result costs ~15-20 ms of host time (pickle + CRC32 + copy into the zip
-    container), almost all of it with the GIL released: writer THREADS scale (measured 29 -> 233 -> 368 files/s
-    with 1 / 2 / 4 threads on 8 busy cores), so the pool is sized from the host: 440 files/s keep one MI355X
-    busy at L = 1022."""
-    return max(2, min(24, (os.cpu_count() or 4) // 4))
+    """``torch.save`` of a 5 MB per-sequence result costs ~4 ms of host time (pickle + CRC32 + copy into the zip
+    container), most of it with the GIL released, so writer THREADS scale — up to a point: 277 / 558 / 1063 / 993 /
+    912 files/s with 1 / 2 / 4 / 8 / 16 threads on an idle 8-core host, and 24 threads on the 256-thread GPU host
+    were slower than 8 (the pickling parts hold the GIL: more threads, longer convoys).  440 files/s keep one
+    MI355X busy at L = 1022."""
+    return max(2, min(8, (os.cpu_count() or 4) // 2))
 
 
 class _Writer:
@@ -207,9 +208,15 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
     def finish(ids, labels, strs, reps, contacts, means_b):
         """Per-sequence results of one batch from HOST tensors (reference scripts/extract.py:104-131)."""
         rows_idx, rows_mean = [], {l: [] for l in layers}
-        # slices are cloned only when they are kept (saved): torch.save of a view would write the whole batch,
-        # and a 5 MB clone per sequence costs more host time (fresh pages) than the device->host copy itself
-        own = (lambda t: t.clone()) if output_dir is not None else (lambda t: t)
+        # torch.save of a VIEW writes the view's whole storage (the batch).  A slice [row, a:b] of the contiguous
+        # host tensor is itself one contiguous run of memory: re-wrapping it (numpy view -> from_numpy; bf16 goes
+        # through its int16 bit pattern) yields a tensor whose storage is exactly the slice, with no 5 MB copy.
+        def own(t):
+            if output_dir is None or not t.is_contiguous() or t.numel() == 0:
+                return t.clone() if output_dir is not None else t
+            if t.dtype == torch.bfloat16:
+                return torch.from_numpy(t.view(torch.int16).numpy()).view(torch.bfloat16)
+            return torch.from_numpy(t.numpy())
         for row, (seq_id, label) in enumerate(zip(ids, labels)):
             n = min(truncation_seq_length, len(strs[row]))
             result = {"label": label}

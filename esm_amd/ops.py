@@ -66,9 +66,21 @@ def linear(a, w, bias=None, epilogue=N.EPI_STORE_T, out=None, force_generic=Fals
     return out
 
 
+LOG2E = 1.4426950408889634
+
+
+def to_log2_domain(q, dtype=None):
+    """The attention kernels take q with log2(e) folded in (the engine's QKV epilogue does that in fp32 before the
+    single rounding to the operand dtype).  Returns (q_kernel, q_effective): the operand-dtype tensor to hand to the
+    kernels and the fp32 natural-domain q it represents exactly (q_kernel / log2 e) — what a reference must use."""
+    qk = (q.float() * LOG2E).to(dtype or q.dtype)
+    return qk, qk.float() / LOG2E
+
+
 def attention(q, k, vt, key_bias=None, want_lse=False):
-    """softmax(q k^T + key_bias) v for head_dim 64.  q,k [B,H,T,64]; vt [B,H,64,Tp] (layout of
-    the fused QKV epilogue, see csrc/attention.hip).  Returns ctx [B*T, H*64] (+ lse [B,H,T])."""
+    """softmax(q k^T + key_bias) v for head_dim 64.  q [B,H,T,64] in the LOG2 domain (``to_log2_domain``), k
+    [B,H,T,64]; vt [B,H,64,Tp] (layout of the fused QKV epilogue, see csrc/attention.hip).  Returns ctx
+    [B*T, H*64] (+ the row log-sum-exp converted to the natural log, [B,H,T])."""
     _req_cuda(q, k, vt, key_bias)
     B, H, T, D = q.shape
     assert D == 64 and vt.shape[-1] == (T + 63) // 64 * 64
@@ -76,11 +88,13 @@ def attention(q, k, vt, key_bias=None, want_lse=False):
     lse = torch.empty((B, H, T), dtype=torch.float32, device=q.device) if want_lse else None
     N.check(N.lib.esmk_op_attention(N.ptr(q), N.ptr(k), N.ptr(vt), N.ptr(key_bias), N.ptr(ctx), N.ptr(lse),
                                     B, H, T, N.dtype_code(q.dtype), N.cur_stream()))
-    return (ctx, lse) if want_lse else ctx
+    return (ctx, lse / LOG2E) if want_lse else ctx  # the kernel's lse is log2-domain
 
 
 def attention_probs(q, k, lse, key_bias=None, out=None, layer=0, num_layers=1):
+    """q in the log2 domain; lse: natural-log row log-sum-exp as returned by ``attention(..., want_lse=True)``."""
     _req_cuda(q, k, lse, key_bias, out)
+    lse = (lse * LOG2E).contiguous()
     B, H, T, D = q.shape
     if out is None:
         out = torch.empty((B, num_layers, H, T, T), dtype=torch.float32, device=q.device)

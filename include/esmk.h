@@ -222,6 +222,10 @@ int esmk_op_qkv_rope(esmk_model* m, const void* a_dev, const void* wqkv_dev,
                      void* stream);
 
 /* softmax(q k^T + key_bias) v  (multihead_attention.py:357-394), flash style.
+ * SCORE DOMAIN: q must carry log2(e) besides d^-1/2 (esmk_forward's QKV epilogue folds both into the q scale
+ * before the single rounding to the operand dtype); q.k is then the score in the log2 domain, the kernel's
+ * exponentials are exp2, and lse_out is the row log2-sum-exp2 (= natural lse * log2 e).
+ * esmk_op_attention_probs takes the same q and that lse.  (esmk_op_qkv_rope scales q by d^-1/2 only.)
  * key_bias fp32 [B,T] (0 or -inf, NULL = no padding); ctx_out [B*T, H*64] operand dtype;
  * lse_out fp32 [B,H,T] or NULL. */
 int esmk_op_attention(const void* q_dev, const void* k_dev, const void* vt_dev,

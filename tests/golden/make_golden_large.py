@@ -1,7 +1,7 @@
 """Full-size golden fixtures for BASELINE configs 3 and 5, produced by the REFERENCE implementation
 (/root/reference/esm imported read-only; only runs where it is mounted).
 
-    python tests/golden/make_golden_large.py [--only=msa1b_config5|esm2_3b_T258|esm2_3b_padded]
+    python tests/golden/make_golden_large.py [--only=msa1b_config5|msa1b_config5_g1|esm2_3b_T258|esm2_3b_padded]
 
 The reference needs minutes (MSA config 5: ~5 min, 3B at T=1024 with attention maps: ~15 min on 8 vCPU) and
 tens of GB, and its outputs are GBs (`attentions [2,36,40,1024,1024]`), so the fixtures are SLIM: full contact
@@ -149,13 +149,17 @@ def check_contact_head_is_per_sequence(ref):
     assert (per - full["contacts"]).abs().max().item() < 1e-6  # reduction order of the batched sums only
 
 
-def make_msa_config5(ref):
+def make_msa_config5(ref, qk_gain=2.0):
+    """qk_gain = 2 (the synthetic-weight default, esm_amd/synth.py) gives extremely sharp tied row attention at
+    depth 128 (mean row maximum 0.46 ... 0.71 per layer): a STRESS case in which the network amplifies any
+    perturbation ~15x per 12 layers and 16-bit operands cannot hold 1e-3 (tools/msa_precision_study.py).
+    qk_gain = 1 is the calibrated case: row maxima 0.03 ... 0.13, no amplification."""
     from esm_amd.synth import MSA_DIMS, synth_msa_state_dict, synth_msa_tokens
 
     L, E, H, F = MSA_DIMS["esm_msa1b_t12_100M_UR50S"]
     seed = 41
     t0 = time.time()
-    sd = synth_msa_state_dict(L, E, H, F, seed=seed)
+    sd = synth_msa_state_dict(L, E, H, F, seed=seed, qk_gain=qk_gain)
     alphabet = ref.Alphabet.from_architecture("msa_transformer")
     args = argparse.Namespace(layers=L, embed_dim=E, ffn_embed_dim=F, attention_heads=H, dropout=0.1,
                               attention_dropout=0.1, activation_dropout=0.1, max_positions=1024,
@@ -167,7 +171,8 @@ def make_msa_config5(ref):
     with torch.no_grad():
         out = model(toks, repr_layers=[L], return_contacts=True)
     fix = slim_msa(out, L)
-    fix.update(dims=dict(L=L, E=E, H=H, F=F, seed=seed), tokens=toks.to(torch.int8), weights_checksum=checksum(sd),
+    fix.update(dims=dict(L=L, E=E, H=H, F=F, seed=seed, qk_gain=qk_gain), tokens=toks.to(torch.int8),
+               weights_checksum=checksum(sd),
                reference_version=getattr(ref, "__version__", "?"), torch_version=torch.__version__,
                seconds=time.time() - t0)
     return fix
@@ -177,10 +182,13 @@ def main():
     only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
     ref = import_reference()
     check_contact_head_is_per_sequence(ref)
-    for case in ("msa1b_config5", "esm2_3b_T258", "esm2_3b_padded"):
+    for case in ("msa1b_config5", "msa1b_config5_g1", "esm2_3b_T258", "esm2_3b_padded"):
         if only and case not in only:
             continue
-        fix = make_msa_config5(ref) if case == "msa1b_config5" else make_esm2_3b(ref, case)
+        if case.startswith("msa1b"):
+            fix = make_msa_config5(ref, qk_gain=1.0 if case.endswith("_g1") else 2.0)
+        else:
+            fix = make_esm2_3b(ref, case)
         path = os.path.join(HERE, f"large_{case}.pt")
         torch.save(fix, path)
         print(case, "->", path, os.path.getsize(path) // 1024, "KiB", f"{fix['seconds']:.0f} s", flush=True)

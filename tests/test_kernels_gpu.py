@@ -169,7 +169,8 @@ def _attn_ref(q, k, v, key_bias):
 def test_attention(ops, B, H, T, pad, dt):
     g = torch.Generator(device="cuda").manual_seed(4)
     # scores with a usable dynamic range (row max of softmax well above uniform)
-    q = (torch.randn(B, H, T, 64, device="cuda", generator=g) * 0.6).to(dt)
+    # the kernels take q with log2(e) folded in; `q` below is the natural-domain q that operand represents exactly
+    qk, q = ops.to_log2_domain(torch.randn(B, H, T, 64, device="cuda", generator=g) * 0.6, dt)
     k = (torch.randn(B, H, T, 64, device="cuda", generator=g) * 0.6).to(dt)
     v = torch.randn(B, H, T, 64, device="cuda", generator=g).to(dt)
     key_bias = None
@@ -179,7 +180,7 @@ def test_attention(ops, B, H, T, pad, dt):
         if B > 1:
             key_bias[1, 3] = float("-inf")      # an interior pad on sequence 1
     vt = ops.make_vt(v)
-    ctx, lse = ops.attention(q, k, vt, key_bias, want_lse=True)
+    ctx, lse = ops.attention(qk, k, vt, key_bias, want_lse=True)
     p_ref, o_ref = _attn_ref(q, k, v, key_bias)
     o_ref = o_ref.permute(0, 2, 1, 3).reshape(B * T, H * 64)
     err = (ctx.float() - o_ref).abs().max().item()
@@ -189,7 +190,7 @@ def test_attention(ops, B, H, T, pad, dt):
         s = s + key_bias[:, None, None, :]
     lse_ref = torch.logsumexp(s, dim=-1)
     assert (lse - lse_ref).abs().max().item() < 1e-3
-    probs = ops.attention_probs(q, k, lse, key_bias)
+    probs = ops.attention_probs(qk, k, lse, key_bias)
     if key_bias is not None:
         keep = (key_bias == 0).float()
         p_ref = p_ref * keep[:, None, :, None] * keep[:, None, None, :]
@@ -206,12 +207,39 @@ def test_attention_rescale_spike(ops):
     k = (torch.randn(B, H, T, 64, device="cuda", generator=g) * 0.3)
     k[0, 0, 400] = q[0, 0, 17] * 40.0
     k[0, 0, 130] = q[0, 0, 300] * 25.0
-    q, k = q.half(), k.half()
+    (qk, q), k = ops.to_log2_domain(q, torch.float16), k.half()
     v = torch.randn(B, H, T, 64, device="cuda", generator=g).half()
-    ctx = ops.attention(q, k, ops.make_vt(v))
+    ctx = ops.attention(qk, k, ops.make_vt(v))
     _, o_ref = _attn_ref(q, k, v, None)
     o_ref = o_ref.permute(0, 2, 1, 3).reshape(B * T, H * 64)
     assert (ctx.float() - o_ref).abs().max().item() < 4 * _eps(torch.float16) * max(1.0, o_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("scale", [0.6, 4.0])
+def test_attention_lazy_offset_edge_cases(ops, scale):
+    """The flash kernel moves its exponent offset only when it has to (attention.hip, LAZY): exercise the
+    bookkeeping — a first key tile that is ENTIRELY masked (no finite score yet), rows whose early scores are far
+    below later ones (offset must move up, by a lot at scale 4: raw scores of +-100), and rows whose later scores are
+    far below the first tile's (offset stays; tiny probabilities)."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B, H, T = 2, 2, 448
+    q = (torch.randn(B, H, T, 64, device="cuda", generator=g) * scale)
+    k = (torch.randn(B, H, T, 64, device="cuda", generator=g) * 0.5)
+    k[0, :, 256:] *= 0.02          # sequence 0: late keys score ~0, early ones dominate or are hugely negative
+    k[1, :, :128] *= 0.02          # sequence 1: the first two tiles score ~0, later keys dominate
+    (qk, q), k = ops.to_log2_domain(q, torch.float16), k.half()
+    v = torch.randn(B, H, T, 64, device="cuda", generator=g).half()
+    key_bias = torch.zeros(B, T, device="cuda")
+    key_bias[0, :70] = float("-inf")   # the whole first 64-key tile (and a bit) of sequence 0 is padding
+    key_bias[1, 5] = float("-inf")
+    ctx, lse = ops.attention(qk, k, ops.make_vt(v), key_bias, want_lse=True)
+    p_ref, o_ref = _attn_ref(q, k, v, key_bias)
+    o_ref = o_ref.permute(0, 2, 1, 3).reshape(B * T, H * 64)
+    assert torch.isfinite(ctx).all()
+    assert (ctx.float() - o_ref).abs().max().item() < 4 * _eps(torch.float16) * max(1.0, o_ref.abs().max().item())
+    s = q.float() @ k.float().transpose(-1, -2) + key_bias[:, None, None, :]
+    lse_ref = torch.logsumexp(s, dim=-1)
+    assert (lse - lse_ref).abs().max().item() < 2e-3 * max(1.0, lse_ref.abs().max().item())
 
 
 @pytest.mark.parametrize("B,L,H,T", [(2, 2, 3, 40), (1, 1, 2, 130)])

@@ -19,10 +19,11 @@ from oracle.esm2_oracle import esm2_forward
 pytestmark = pytest.mark.gpu
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "esm2_*.pt")))  # incl. head_dim 16 (8M)
 REL = 1e-3
-# Deep stacks (33-36 layers) with fp16 operands measure 1.1-1.2e-3 on the seeded synthetic weights
-# (11-bit operand mantissas: ~2.8e-4 rms per rounding, ~12 roundings per layer); the bound below
-# is what the tests enforce, the achieved values are printed and recorded in DESIGN.md.
-REL_DEEP = 1.5e-3
+# Deep stacks (33-36 layers) with fp16 operands: the contract itself.  Measured on the MI355X (round 2):
+# representations[33] 9.0e-4 / 9.3e-4 (650M dims, T = 256 padded / T = 1024), representations[36] 8.5e-4 ... 9.7e-4
+# (3B dims, T = 96 / 258 / 1024); DESIGN.md §2 has the table.  Logits are compared at 2e-3 (1.3 - 1.5e-3 measured:
+# one more fp16-operand GEMM + LayerNorm on top of the representation) and through the token argmax.
+REL_DEEP = 1e-3
 # Few-layer fixtures: the exact embedding is a small part of the stream, so the per-layer rounding
 # error is seen undiluted (a pure operand-rounding emulation of the reference on the same weights
 # gives 1.1-1.3e-3 on tiny_d64); 2e-3 bounds it.
@@ -119,7 +120,7 @@ def test_650m_dims_against_oracle(B, T, padded):
           f"argmax raw agreement {raw:.4f}")
     assert errs[0] < 1e-6
     assert all(e < REL_DEEP for e in errs.values()), errs
-    assert lerr < REL_DEEP * 2
+    assert lerr < 2e-3
     assert decided_ok and raw > 0.98
 
 

@@ -17,6 +17,7 @@ for d in trace; do
   [ -n "$db" ] && python tools/rocpd_summary.py $db > $OUT/kernel_stats.md 2>&1
 done
 python tools/rocpd_pmc.py $(ls $OUT/pmc_*/*/*_results.db $OUT/pmc_*/*_results.db 2>/dev/null) > $OUT/pmc_summary.txt 2>&1
+python tools/pmc_summary.py $OUT/pmc_summary.json $(ls $OUT/pmc_*/*/*_results.db $OUT/pmc_*/*_results.db 2>/dev/null) > $OUT/pmc_summary_json.log 2>&1
 ls -R $OUT | head -40 > $OUT/files.txt
 # the raw traces are large: keep only the summaries
 find $OUT -name "*.db" -size +20M -delete
