@@ -523,6 +523,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out-dir", default=None, help="extract_650m: directory (file system) the result files go to")
     ap.add_argument("--writer-threads", type=int, default=0, help="extract_650m: writer threads (0 = from host cores)")
+    ap.add_argument("--operand", choices=["f16", "bf16"], default=None,
+                    help="MFMA operand type (default f16: the only one inside the 1e-3 contract; bf16 is ~4 %% faster at "
+                         "~7e-3 relative error).  Sets ESM_AMD_OPERAND for this run.")
     ap.add_argument("--spawn", action="store_true",
                     help="go through the self-launch path even for --gpus 1 (tests: the N = 1 run then initialises RCCL "
                          "exactly as an N > 1 run does)")
@@ -533,6 +536,8 @@ def main():
 
     from esm_amd.launch import init_ranks, relaunch, under_launcher
 
+    if args.operand:
+        os.environ["ESM_AMD_OPERAND"] = args.operand
     if (args.gpus > 1 or args.spawn) and not under_launcher():
         os.environ["ESM_AMD_BENCH_LAUNCH"] = "self-spawned"
         raise SystemExit(relaunch(args.gpus, os.path.abspath(__file__), sys.argv[1:]))

@@ -70,6 +70,13 @@ ESMK_DEV void attn_barrier() {
 // exp + add + cvt (~4).
 constexpr float LAZY_LIMIT = 4096.f;
 
+// Round-2 experiments on top of LAZY = 1, measured on the bench shape and removed again (profiles/r2_attention_*):
+// alternating the two accumulators of a phase instead of two chains of four dependent MFMAs, s_setprio 1 around the
+// MFMA clusters (all within +-1 %), and a software-pipelined single-wave schedule (QK^T of tile t+1 and P.V of tile
+// t-1 issued in one basic block with the exponentials of tile t; 200+ VGPRs -> 2 waves per SIMD): 15.5 vs 13.1 ms
+// per step.  The PMC pass shows why: VALU-port time (711 cycles per wave and tile) plus matrix-pipe time (512)
+// add up to the kernel's duration — the limiter is how well the hardware interleaves the waves of a SIMD, which a
+// third resident wave helps more than in-wave scheduling.
 template <typename T, int LAZY>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
@@ -347,304 +354,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
     if (lse != nullptr && h == 0 && qrow < Tseg) lse[rbase + qrow] = m_off + log2f(ltot);
 }
 
-// ---------------------------------------------------------------------------------------------
-// attn_fwd_pipe_kernel: the same math as attn_fwd_kernel<LAZY = 1>, software-pipelined so that the matrix pipe
-// and the VALU of ONE wave work on different key tiles at the same time.  Iteration t issues, as independent
-// instruction streams of one basic block,
-//     QK^T of tile t+1 (8 MFMAs, into the other score registers)   — needs only K(t+1) and Q
-//     P.V   of tile t-1 (8 MFMAs, with the probabilities kept from the previous iteration)
-//     exp2 / row sum / fp16 packing of tile t (32 v_exp + 32 v_add + 16 v_cvt_pk)
-// i.e. 16 MFMAs (512 matrix-pipe cycles) next to ~450 cycles of VALU issue: two scores' worth of softmax (2 exp,
-// 2 add, 1 cvt_pk) fit beside each MFMA.  attn_fwd_kernel runs the three phases back to back in every wave and
-// relies on the other waves of the SIMD being out of phase; its PMC profile shows MFMA-busy + VALU-busy ~ 92 %,
-// i.e. hardly any overlap (profiles/r1_v20_attention_pmc.txt).
-// The lazy-offset bookkeeping is unchanged; when the exact path moves the offset in iteration t, the scores of
-// tile t+1 (already computed against the old offset) are shifted by the same amount.
-// LDS: K tiles double buffered (K(t+2) lands while QK^T(t+1) reads), V^T tiles in a ring of three (V(t-1) is read
-// while V(t+1) lands), key-bias rows in a ring of three: 2 x 8 + 3 x 8 KiB + 768 B.
-// ---------------------------------------------------------------------------------------------
-constexpr int PIPE_LDS = 2 * A_TILE + 3 * A_TILE + 3 * 256;
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(
-    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
-    const float* __restrict__ key_bias, const int* __restrict__ seq_info, T* __restrict__ ctx,
-    float* __restrict__ lse, int H, int BH, int nq, int Tlen, int Tp, int xcdmap, int fill_mode,
-    const int* __restrict__ any_pad, AttnSegs segs) {
-    __shared__ __attribute__((aligned(16))) char smem[PIPE_LDS];
-    using V8 = typename Op<T>::v8;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, lm = lane & 31;
-    int bh, qblk;
-    {
-        const int id = blockIdx.x;
-        const int bh8 = xcdmap ? (BH & ~7) : 0;
-        if (id < bh8 * nq) {
-            const int r = id >> 3;
-            qblk = r % nq;
-            bh = (r / nq) * 8 + (id & 7);
-        } else {
-            const int r = id - bh8 * nq;
-            bh = bh8 + r / nq;
-            qblk = r % nq;
-        }
-    }
-    const int b = bh / H, head = bh - b * H;
-    int row0 = 0, Tseg = Tlen, qrel = qblk * 128;
-    bool seg_pad = false;
-    if (segs.work != nullptr) {  // token-packed batch: see attn_fwd_kernel
-        row0 = __builtin_amdgcn_readfirstlane(segs.work[4 * qblk]);
-        Tseg = __builtin_amdgcn_readfirstlane(segs.work[4 * qblk + 1]);
-        qrel = __builtin_amdgcn_readfirstlane(segs.work[4 * qblk + 2]);
-        seg_pad = segs.npad[__builtin_amdgcn_readfirstlane(segs.work[4 * qblk + 3])] > 0;
-    }
-    const int q0 = qrel + wave * 32;
-    const size_t rbase = (size_t)bh * Tlen + row0;
-
-    int kv_end = Tseg;
-    bool use_mask = (Tseg & 63) != 0;
-    if (segs.work != nullptr) {
-        if (seg_pad) use_mask = true;
-        else key_bias = nullptr;
-    } else if (fill_mode) {
-        if (key_bias != nullptr && any_pad != nullptr && any_pad[0] != 0) use_mask = true;
-        else key_bias = nullptr;
-    } else if (key_bias != nullptr) {
-        if (seq_info != nullptr) {
-            if (seq_info[2 * b] > 0) {
-                use_mask = true;
-                kv_end = seq_info[2 * b + 1];
-            }
-        } else {
-            use_mask = true;
-        }
-    }
-    const int ntiles = (kv_end + 63) >> 6;
-
-    const T* kb = k + rbase * 64;
-    const T* vb = vt + (size_t)bh * 64 * Tp + row0;
-
-    V8 qf[4];
-    {
-        const int qr = min(q0 + lm, Tseg - 1);
-        const T* qp = q + (rbase + qr) * 64 + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qp + 16 * ks);
-    }
-
-    char* const lds_k = smem;                    // 2 K tiles
-    char* const lds_v = smem + 2 * A_TILE;       // 3 V^T tiles
-    float* const lds_b = reinterpret_cast<float*>(smem + 5 * A_TILE);  // 3 key-bias rows of 64
-    const int r0 = tid >> 3;
-    const int kcol = ((tid & 7) ^ ((r0 >> 1) & 7)) * 8;
-    const int voff = r0 * Tp + kcol;
-    auto stage_k = [&](int kt) {  // K tile kt and its key-bias row
-        char* base = lds_k + (kt & 1) * A_TILE;
-        const int k0 = kt * 64;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int kr = min(k0 + r0 + 32 * j, Tseg - 1);
-            glds16(kb + (size_t)kr * 64 + kcol, base + (j * 256 + wave * 64) * 16);
-        }
-        if (use_mask && tid < 64) {
-            const int key = k0 + tid;
-            float bv = -INFINITY;
-            if (key < Tseg) {
-                bv = key_bias ? key_bias[(size_t)b * Tlen + row0 + key] : 0.f;
-                if (fill_mode) bv = (bv != 0.f) ? INFINITY : 0.f;
-            }
-            lds_b[(kt % 3) * 64 + tid] = bv;
-        }
-    };
-    auto stage_v = [&](int kt) {
-        char* base = lds_v + (kt % 3) * A_TILE;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            glds16(vb + (size_t)(voff + 32 * j * Tp) + kt * 64, base + (j * 256 + wave * 64) * 16);
-    };
-
-    const int lrow = lm * 128;
-    const int swz = (lane >> 1) & 7;
-    int xo[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) xo[c] = lrow + (((2 * c + h) ^ swz) << 4);
-
-    f32x16 o[2];
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_off = 0.f, lsum = 0.f;
-    bool m_ok = false;
-    f32x16 negm;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
-
-    // scores of one 64-key tile against the current offset: st = K . Q^T - m_off
-    auto qk_tile = [&](int kt, f32x16 (&st)[2]) {
-        const char* sk = lds_k + (kt & 1) * A_TILE;
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-            st[t2] = Op<T>::mma_keep_c(*reinterpret_cast<const V8*>(sk + t2 * 4096 + xo[0]), qf[0], negm);
-#pragma unroll
-            for (int ks = 1; ks < 4; ++ks)
-                st[t2] = Op<T>::mma(*reinterpret_cast<const V8*>(sk + t2 * 4096 + xo[ks]), qf[ks], st[t2]);
-        }
-    };
-    auto pv_tile = [&](int kt, const V8 (&pf)[4]) {
-        const char* sv = lds_v + (kt % 3) * A_TILE;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                o[d] = Op<T>::mma(*reinterpret_cast<const V8*>(sv + d * 4096 + xo[kk]), pf[kk], o[d]);
-    };
-
-    // one iteration: scores of tile kt are in `sc`; its probabilities go to `pc`; `sn` receives the scores of
-    // tile kt+1 (unless LAST) and `pp` holds the probabilities of tile kt-1 (zeros for kt = 0, multiplied into the
-    // zeroed ring slot 2).  No branch between the MFMAs and the exponentials: one basic block for the scheduler.
-    auto body = [&](auto last_tag, int kt, f32x16 (&sc)[2], f32x16 (&sn)[2], V8 (&pc)[4], const V8 (&pp)[4]) {
-        constexpr bool LAST = decltype(last_tag)::value;
-        if (kt + 2 < ntiles) stage_k(kt + 2);
-        if (kt + 1 < ntiles) stage_v(kt + 1);
-        if (use_mask) {
-            const float* sb = lds_b + (kt % 3) * 64;
-            const float fillv = -10000.f * LOG2E - m_off;
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(sb + t2 * 32 + 8 * g + 4 * h);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        sc[t2][4 * g + e] = (bv[e] == INFINITY) ? fillv : sc[t2][4 * g + e] + bv[e];
-                }
-        }
-        // ---- the pipelined block: three independent streams -------------------------------------------
-        if constexpr (!LAST) qk_tile(kt + 1, sn);
-        pv_tile(kt + 2, pp);  // ring slot (kt + 2) % 3 == (kt - 1) % 3
-        float ps = 0.f;
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float p = __builtin_amdgcn_exp2f(sc[t2][8 * ks + e]);
-                    ps += p;
-                    pc[2 * t2 + ks][e] = Op<T>::from(p);
-                }
-        // fast path valid only if every row already has a finite offset and nothing ran away from it
-        const bool exact = __builtin_amdgcn_ballot_w64(!m_ok || !(ps <= LAZY_LIMIT)) != 0;
-        if (!exact) {
-            lsum += ps;
-        } else {
-            float mx = sc[0][0];
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[t2][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float delta = m_ok ? fmaxf(mx, 0.f) : (mx == -INFINITY ? 0.f : mx);
-            const float alpha = m_ok ? __builtin_amdgcn_exp2f(-delta) : 1.f;
-            m_ok = m_ok || (mx != -INFINITY);
-            float pse = 0.f;
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float p = __builtin_amdgcn_exp2f(sc[t2][8 * ks + e] - delta);
-                        pse += p;
-                        pc[2 * t2 + ks][e] = Op<T>::from(p);
-                    }
-            lsum = lsum * alpha + pse;
-            // O^T already holds tile kt-1 (program order): everything accumulated so far is relative to the old offset
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            if constexpr (!LAST) {  // the scores of tile kt+1 were computed against the old offset
-#pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sn[t2][r] -= delta;
-            }
-            m_off += delta;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) negm[r] = -m_off;
-        }
-        wait_vmcnt0();
-        __syncthreads();
-    };
-
-    // prologue: K(0), K(1), V(0) resident, V ring slot 2 zeroed (tile "-1"); scores of tile 0
-    stage_k(0);
-    if (ntiles > 1) stage_k(1);
-    stage_v(0);
-    {
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        reinterpret_cast<f32x4*>(lds_v + 2 * A_TILE)[tid] = z;
-        reinterpret_cast<f32x4*>(lds_v + 2 * A_TILE)[tid + 256] = z;
-    }
-    wait_vmcnt0();
-    __syncthreads();
-    f32x16 sa[2], sb2[2];
-    V8 pa[4], pb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            pa[i][e] = Op<T>::from(0.f);
-            pb[i][e] = Op<T>::from(0.f);
-        }
-    qk_tile(0, sa);
-    using NotLast = std::integral_constant<bool, false>;
-    using Last = std::integral_constant<bool, true>;
-    int kt = 0;
-    for (; kt + 2 < ntiles; kt += 2) {
-        body(NotLast(), kt, sa, sb2, pa, pb);
-        body(NotLast(), kt + 1, sb2, sa, pb, pa);
-    }
-    const bool two_left = kt + 2 == ntiles;  // wave uniform
-    if (two_left) {
-        body(NotLast(), kt, sa, sb2, pa, pb);
-        body(Last(), kt + 1, sb2, sa, pb, pa);
-    } else {
-        body(Last(), kt, sa, sb2, pa, pb);
-    }
-    // the last tile's P.V
-    if (two_left) pv_tile(ntiles - 1, pb);
-    else pv_tile(ntiles - 1, pa);
-    __syncthreads();  // every wave is done with the K / V^T buffers (the epilogue reuses the LDS)
-
-    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
-    const float inv = 1.0f / ltot;
-    using V4 = typename Op<T>::v4;
-    char* wl = smem + wave * 4096;
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            V4 pk;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pk[e] = Op<T>::from(o[d][4 * g + e] * inv);
-            *reinterpret_cast<V4*>(wl + lm * 128 + (((4 * d + g) ^ (lm & 7)) << 4) + 8 * h) = pk;
-        }
-    T* dst = ctx + ((size_t)b * Tlen + row0) * ((size_t)H * 64) + head * 64;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int pc = it * 64 + lane;
-        const int r = pc >> 3, c = pc & 7;
-        const V8 v = *reinterpret_cast<const V8*>(wl + r * 128 + ((c ^ (r & 7)) << 4));
-        if (q0 + r < Tseg) *reinterpret_cast<V8*>(dst + (size_t)(q0 + r) * ((size_t)H * 64) + c * 8) = v;
-    }
-    const int qrow = q0 + lm;
-    if (lse != nullptr && h == 0 && qrow < Tseg) lse[rbase + qrow] = m_off + log2f(ltot);
-}
-
 static hipError_t launch_attention_impl(const void* q, const void* k, const void* vt, const float* key_bias,
                                         const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
                                         int operand_dtype, int fill_mode, const int* any_pad, hipStream_t st,
@@ -679,7 +388,7 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
     const int nq = segs.work != nullptr ? n_items : (T + 127) / 128;
     dim3 grid(nq * B * H);
     // ESMK_ATTN (read once): bit 0 XCD-grouped grid (default on), bit 1 = textbook online softmax instead of the
-    // lazy-offset one, bit 2 = software-pipelined kernel (A/B measurements; all are exact softmax)
+    // lazy-offset one (A/B measurements; both are exact softmax)
     static const int var = [] {
         const char* e = getenv("ESMK_ATTN");
         return e ? atoi(e) : ATTN_DEFAULT_VARIANT;
@@ -687,19 +396,13 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
 #define ESMK_ATTN_LAUNCH(TT, LZ)                                                                      \
     hipLaunchKernelGGL((attn_fwd_kernel<TT, LZ>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k,   \
                        (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad, segs)
-#define ESMK_ATTN_PIPE(TT)                                                                            \
-    hipLaunchKernelGGL((attn_fwd_pipe_kernel<TT>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k,  \
-                       (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad, segs)
     if (operand_dtype == ESMK_DT_BF16) {
-        if (var & 4) ESMK_ATTN_PIPE(__bf16);
-        else if (var & 2) ESMK_ATTN_LAUNCH(__bf16, 0);
+        if (var & 2) ESMK_ATTN_LAUNCH(__bf16, 0);
         else ESMK_ATTN_LAUNCH(__bf16, 1);
     } else {
-        if (var & 4) ESMK_ATTN_PIPE(_Float16);
-        else if (var & 2) ESMK_ATTN_LAUNCH(_Float16, 0);
+        if (var & 2) ESMK_ATTN_LAUNCH(_Float16, 0);
         else ESMK_ATTN_LAUNCH(_Float16, 1);
     }
-#undef ESMK_ATTN_PIPE
 #undef ESMK_ATTN_LAUNCH
     return hipGetLastError();
 }
