@@ -7,6 +7,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 namespace esmk {
 
 // ---------------------------------------------------------------------------------------------
@@ -796,8 +798,13 @@ __global__ __launch_bounds__(256) void msa_embed_kernel(const int64_t* __restric
                                                          float* __restrict__ col_fill,
                                                          int* __restrict__ any_pad, int R, int C, int D,
                                                          int vocab, int pad_idx, int npos) {
+    // grid (B*R, column chunks): one workgroup per MSA row left 128 of the 256 CUs idle and serialised 1.5 MB of
+    // stores per workgroup (346 us for a 128 x 513 MSA); every chunk recomputes the row's (cheap) position scan
+    // and writes only its own columns.
     extern __shared__ int s_pos[];  // [C] position ids, then 4 wave totals
     const int br = blockIdx.x;      // b * R + r
+    const int cper = (C + gridDim.y - 1) / gridDim.y;
+    const int c_lo = blockIdx.y * cper, c_hi = min(C, c_lo + cper);
     const int b = br / R, r = br - b * R;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t* row = tokens + (size_t)br * C;
@@ -821,17 +828,19 @@ __global__ __launch_bounds__(256) void msa_embed_kernel(const int64_t* __restric
         for (int w = 0; w < wave; ++w) base += s_tot[w];
         if (c < C) {
             s_pos[c] = (v + base) * np + pad_idx;
-            keep[(size_t)br * C + c] = (float)np;
-            col_fill[((size_t)b * C + c) * R + r] = np ? 0.f : 1.f;
+            if (c >= c_lo && c < c_hi) {
+                keep[(size_t)br * C + c] = (float)np;
+                col_fill[((size_t)b * C + c) * R + r] = np ? 0.f : 1.f;
+            }
         }
         carry += s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
         __syncthreads();
     }
-    if (saw_pad) atomicOr(any_pad, 1);
+    if (saw_pad && blockIdx.y == 0) atomicOr(any_pad, 1);
     const int d4 = D >> 2;
     const f32x4* mp = msa_pos ? reinterpret_cast<const f32x4*>(msa_pos + (size_t)r * D) : nullptr;
-    for (int idx = tid; idx < C * d4; idx += 256) {
-        const int c = idx / d4, k = idx - c * d4;
+    for (int idx = tid; idx < (c_hi - c_lo) * d4; idx += 256) {
+        const int c = c_lo + idx / d4, k = idx % d4;
         const int64_t tok = row[c];
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (tok >= 0 && tok < vocab) v = reinterpret_cast<const f32x4*>(tok_emb + (size_t)tok * D)[k];
@@ -854,7 +863,8 @@ hipError_t launch_msa_embed(const int64_t* tokens, const float* tok_emb, const f
     if (D % 4 != 0) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(any_pad, 0, sizeof(int), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(msa_embed_kernel, dim3(B * R), dim3(256), (size_t)(C + 4) * sizeof(int), st, tokens,
+    const unsigned chunks = (unsigned)std::max(1, std::min(16, (C + 63) / 64));
+    hipLaunchKernelGGL(msa_embed_kernel, dim3(B * R, chunks), dim3(256), (size_t)(C + 4) * sizeof(int), st, tokens,
                        tok_emb, pos_emb, msa_pos, x, keep, col_fill, any_pad, R, C, D, vocab, pad_idx, npos);
     return hipGetLastError();
 }
@@ -871,7 +881,8 @@ __global__ __launch_bounds__(256) void msa_row_softmax_kernel(const float* __res
                                                                const int* __restrict__ any_pad,
                                                                T* __restrict__ probs,
                                                                float* __restrict__ attn_out, int B, int H,
-                                                               int R, int C, int ldp, int layer, int Ltot) {
+                                                               int R, int C, int ldp, int layer, int Ltot,
+                                                               int nslice) {
     const int lane = threadIdx.x & 63;
     const int rowid = blockIdx.x * 4 + (threadIdx.x >> 6);  // (b*H + h)*C + i
     const int total = B * H * C;
@@ -879,7 +890,9 @@ __global__ __launch_bounds__(256) void msa_row_softmax_kernel(const float* __res
     const int bh = rowid / C, i = rowid - bh * C;
     const int b = bh / H, h = bh - b * H;
     const bool masked = any_pad[0] != 0;
-    const float* srow = scores + (size_t)rowid * ldp;
+    // scores [B, nslice, H, C, ldp]: the tied contraction over the R rows arrives as nslice partial maps
+    const size_t slice_stride = (size_t)H * C * ldp;
+    const float* srow = scores + ((size_t)b * nslice * H + h) * C * ldp + (size_t)i * ldp;
     const float* k0 = keep + (size_t)b * R * C;  // row 0 of MSA b: keep[b,0,j]
     constexpr int MAXJ = 16;                       // columns per lane: C <= 1024
     float v[MAXJ];
@@ -890,6 +903,7 @@ __global__ __launch_bounds__(256) void msa_row_softmax_kernel(const float* __res
         float s = -INFINITY;
         if (j < C) {
             s = srow[j];
+            for (int sl = 1; sl < nslice; ++sl) s += srow[sl * slice_stride + j];  // fixed order: deterministic
             if (masked && k0[j] == 0.f) s = -10000.f;
         }
         v[q] = s;
@@ -917,15 +931,15 @@ __global__ __launch_bounds__(256) void msa_row_softmax_kernel(const float* __res
 
 hipError_t launch_msa_row_softmax(const float* scores, const float* keep, const int* any_pad, void* probs,
                                   float* attn_out, int B, int H, int R, int C, int ldp, int layer,
-                                  int num_layers_total, int operand_dtype, hipStream_t st) {
-    if (C > 1024 || ldp > 1024 || ldp < C) return hipErrorInvalidValue;
+                                  int num_layers_total, int operand_dtype, hipStream_t st, int nslice) {
+    if (C > 1024 || ldp > 1024 || ldp < C || nslice < 1) return hipErrorInvalidValue;
     dim3 grid((unsigned)((B * H * C + 3) / 4));
     if (operand_dtype == ESMK_DT_BF16)
         hipLaunchKernelGGL((msa_row_softmax_kernel<__bf16>), grid, dim3(256), 0, st, scores, keep, any_pad,
-                           (__bf16*)probs, attn_out, B, H, R, C, ldp, layer, num_layers_total);
+                           (__bf16*)probs, attn_out, B, H, R, C, ldp, layer, num_layers_total, nslice);
     else
         hipLaunchKernelGGL((msa_row_softmax_kernel<_Float16>), grid, dim3(256), 0, st, scores, keep, any_pad,
-                           (_Float16*)probs, attn_out, B, H, R, C, ldp, layer, num_layers_total);
+                           (_Float16*)probs, attn_out, B, H, R, C, ldp, layer, num_layers_total, nslice);
     return hipGetLastError();
 }
 

@@ -65,7 +65,20 @@ struct MsaWorkspace {
     size_t keep, col_fill, any_pad, x, h, big, scores, probs, lse, ct_scratch, total;
     size_t q, k, vt;  // inside big
     int Cp, Rp;
+    int row_slices;  // the tied-score GEMM sums over R rows in this many K slices (partial maps summed by the softmax)
 };
+
+// Tied row attention scores: per (b, head) a [C, C] map contracted over R * 64, i.e. only B * H * ceil(C/256)^2
+// output tiles (108 for one 128 x 513 MSA) with a very long K loop: less than half of the 256 CUs would work.
+// The contraction is cut into `S` slices of R / S rows (S | R), each slice a batch entry of the same persistent
+// GEMM writing its own fp32 partial map; msa_row_softmax_kernel adds the slices in index order (deterministic).
+int row_score_slices(int B, int H, int R, int C) {
+    const int tiles = B * H * ((C + 255) / 256) * ((C + 255) / 256);
+    int best = 1;
+    for (int s = 2; s <= 8 && s * tiles <= 256 + tiles / 2; ++s)
+        if (R % s == 0) best = s;
+    return best;
+}
 
 MsaWorkspace plan_msa_workspace(const esmk_model* m, int B, int R, int C, uint32_t flags) {
     MsaWorkspace w{};
@@ -89,7 +102,8 @@ MsaWorkspace plan_msa_workspace(const esmk_model* m, int B, int R, int C, uint32
     w.q = w.big;
     w.k = w.big + qb;
     w.vt = w.big + 2 * qb;
-    w.scores = c.take((size_t)B * H * C * w.Cp * 4);
+    w.row_slices = row_score_slices(B, (int)H, R, C);
+    w.scores = c.take((size_t)w.row_slices * B * H * C * w.Cp * 4);
     w.probs = c.take((size_t)B * H * C * w.Cp * os);
     w.lse = c.take((flags & ESMK_OUT_COL_ATTN) ? (size_t)B * C * H * R * 4 : 0);
     const int S = C - (m->cfg.prepend_bos ? 1 : 0) - (m->cfg.append_eos ? 1 : 0);
@@ -290,6 +304,8 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
         if (qkv(o.row, C, Cp, (1.0f / sqrtf(64.0f)) / sqrtf((float)R), keep, R)) return 1;
         {   // scores[b,h,i,j] = sum_{r,d} q[r,i,b,h,d] k[r,j,b,h,d]   (axial_attention.py:90): K tile r of
             // the batched GEMM is the [C,64] matrix q[(b,r),h] (row stride 128 B)
+            // slice s of MSA b is batch entry zo = b * S + s: R / S rows further down q / k, its own output map
+            const int S = w.row_slices, Rs = R / S;
             GemmArgs g;
             g.A = q;
             g.W = k;
@@ -297,13 +313,13 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
             g.M = C;
             g.N = Cp;
             g.n_valid = C;
-            g.K = R * 64;
+            g.K = Rs * 64;
             g.ldc = Cp;
             g.a_row_bytes = g.w_row_bytes = 128;
             g.a_kt_bytes = g.w_kt_bytes = (long long)H * C * 64 * os;
-            g.batch = B * H;
+            g.batch = B * S * H;
             g.batch_inner = H;
-            g.a_bo = g.w_bo = (long long)R * H * C * 64 * os;
+            g.a_bo = g.w_bo = (long long)Rs * H * C * 64 * os;
             g.a_bi = g.w_bi = (long long)C * 64 * os;
             g.o_bo = (long long)H * C * Cp * 4;
             g.o_bi = (long long)C * Cp * 4;
@@ -314,7 +330,7 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
             ProfScope ps(m, st, PC_MSA_ROW_SOFTMAX, 0, sc * (4 + os + (want_attn ? 4 : 0)));
             ESMK_TRY(launch_msa_row_softmax(scores, keep, any_pad, probs,
                                             want_attn ? (float*)row_attn_out_dev : nullptr, B, H, R, C, Cp, l, L, op,
-                                            st));
+                                            st, w.row_slices));
         }
         {   // context[r,i,b,h,:] = sum_j probs[h,b,i,j] v[r,j,b,h,:]   (axial_attention.py:111)
             GemmArgs g;

@@ -95,7 +95,7 @@ hipError_t launch_msa_embed(const int64_t* tokens, const float* tok_emb, const f
 // tied row attention softmax (axial_attention.py:96-100,127)
 hipError_t launch_msa_row_softmax(const float* scores, const float* keep, const int* any_pad, void* probs,
                                   float* attn_out, int B, int H, int R, int C, int ldp, int layer,
-                                  int num_layers_total, int operand_dtype, hipStream_t st);
+                                  int num_layers_total, int operand_dtype, hipStream_t st, int nslice = 1);
 // dtype conversion of a parameter tensor into the packed image
 hipError_t launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype, size_t n,
                           hipStream_t st);
