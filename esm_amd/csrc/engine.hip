@@ -872,7 +872,8 @@ int esmk_op_linear(const void* a_dev, const void* w_dev, const float* bias_dev, 
     g.K = K;
     if (operand_dtype & 0x100) g.force_generic = 1;  // test hook: force the generic 64x64 kernel
     if (operand_dtype & 0x200) g.force_old = 1;      // test hook: one-tile-per-workgroup 256x256 kernel
-    g.panel_c = (operand_dtype >> 20) & 0xff;         // tile-order experiments (tools/microbench.py)
+    g.panel_c = (operand_dtype >> 20) & 0x3f;         // tile-order experiments (tools/microbench.py)
+    g.half_m = ((operand_dtype >> 28) & 3) == 1 ? 1 : (((operand_dtype >> 28) & 3) == 2 ? -1 : 0);  // 128-row tiles: force / never
     g.dbg = (operand_dtype >> 12) & 0xff;             // timing experiments (tools/microbench.py)
     operand_dtype &= 0xff;
     ESMK_TRY(launch_gemm(g, epilogue, operand_dtype, (hipStream_t)stream));

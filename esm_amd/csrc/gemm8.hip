@@ -104,7 +104,8 @@ ESMK_DEV typename Op<T>::v4 pack4_(float a, float b, float c, float d) {
 // EPI_V_T, whose bias varies with the lane instead of the register.  FULL = the wave's block lies
 // completely inside [0,M) x [0,N): no store is predicated, so the wave issues exactly
 // epilogue_stores<EPI>() store instructions.
-template <typename T, int EPI, bool FULL, bool NOSTORE = false, bool GEN = false>
+// NI = number of 32-row pieces of the wave's block: 4 (128 rows), or 2 in the half-height tile mode (HM).
+template <typename T, int EPI, bool FULL, bool NOSTORE = false, bool GEN = false, int NI = 4>
 ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int n_base, int lane,
                         char* wl, size_t out_off, int zo, int zi) {
     using V4 = typename Op<T>::v4;
@@ -129,7 +130,7 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
             return ((size_t)(bm * p.H + head) * p.vt_rows + r) * 64;
         };
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             // LDS piece: 64 rows (dv) x 64 B (32 tokens); 16-byte chunk c holds 8 token slots
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -193,7 +194,7 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
         T* qk = reinterpret_cast<T*>(which == 0 ? p.q : p.k);
         const float sc = which == 0 ? p.scaling : 1.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int m = min(m_base + 32 * i + lm, p.M - 1);
             const int t = (GEN && p.row_pos != nullptr) ? p.row_pos[m] : m % p.T;
             // MSA row attention zeroes q at padded positions (axial_attention.py:85-88)
@@ -239,7 +240,7 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
         T* out = reinterpret_cast<T*>(reinterpret_cast<char*>(p.out) + out_off);
         const int ldc = (GEN && p.ldc > 0) ? p.ldc : p.N;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -295,10 +296,10 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
         };
         if constexpr (EPI == EPI_RESID_F32) load_old(old, 0);
 #pragma unroll
-        for (int piece = 0; piece < 8; ++piece) {
+        for (int piece = 0; piece < 2 * NI; ++piece) {
             const int i = piece >> 1, j = piece & 1;
             if constexpr (EPI == EPI_RESID_F32)
-                if (piece + 1 < 8) load_old(nxt, piece + 1);  // residual of the next piece in flight
+                if (piece + 1 < 2 * NI) load_old(nxt, piece + 1);  // residual of the next piece in flight
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v;
@@ -350,8 +351,17 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
 // fabric / HBM latency inside the two-K-tile-deep DMA window).
 // GEN: generalised addressing (strides, batch, row remaps; GemmArgs fields after `scaling`) — a separate
 // instantiation so that the dense layer-stack kernels keep their register budget.
-template <typename T, int EPI, int SCHED = 0, int DBG = 0, int PF = 0, bool GEN = false>
+// HM: half-height tiles (128 x 256).  Everything — LDS units, DMA stream, waits, barriers — stays as it is; the
+// two wave groups own 64 rows each instead of 128, so the matrix sections of phases 2 and 3 (fragments i2, i3) are
+// empty and unit U3 re-stages the rows of U0 (L2 hits, never read).  A tile then costs 0.7 - 0.95 of a full one but
+// there are twice as many: used when 256-row tiles leave most CUs without work (small batches: B = 4 x 1024 tokens has
+// 80 tiles for 256 CUs at N = 1280).  Every output element still sees the same MFMA sequence over K, so the results
+// are bit-identical to the full-height kernel — independent of the batch size.
+template <typename T, int EPI, int SCHED = 0, int DBG = 0, int PF = 0, bool GEN = false, bool HM = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long long* timing) {
+    static_assert(!HM || (SCHED == 0 && !GEN), "half-height tiles: dense layer-stack kernels, schedule 0 only");
+    constexpr int TM = HM ? 128 : 256;  // tile height
+    constexpr int GM = TM / 2;          // rows per wave group
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V8 = typename Op<T>::v8;
     const int tid = threadIdx.x;
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
     const int nbatch = GEN ? p.batch : 1, binner = GEN ? p.batch_inner : 1;
 
     // ---- static persistent schedule -----------------------------------------------------------
-    const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
+    const int tiles_m = (p.M + TM - 1) / TM, tiles_n = (p.N + 255) >> 8;
     const int tiles_mn = tiles_m * tiles_n;
     const int total = tiles_mn * nbatch;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
@@ -408,11 +418,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
         s.it = it;
         s.kt = 0;
         if (unit == 0 || unit == 3) {  // A rows: group (ur>>6) * 128 + (unit 3 ? 64 : 0) + (ur & 63)
-            const int lim = p.M - tmi * 256 - 1;
-            const int add = unit == 3 ? 64 : 0;
-            s.base = reinterpret_cast<const char*>(p.A) + (size_t)tmi * 256 * a_rb + a_boff;
-            s.off0 = (unsigned)min((ur0 >> 6) * 128 + add + (ur0 & 63), lim) * a_rb + cs0;
-            s.off1 = (unsigned)min((ur1 >> 6) * 128 + add + (ur1 & 63), lim) * a_rb + cs1;
+            const int lim = p.M - tmi * TM - 1;
+            const int add = (unit == 3 && !HM) ? 64 : 0;  // HM: U3 repeats the rows of U0
+            s.base = reinterpret_cast<const char*>(p.A) + (size_t)tmi * TM * a_rb + a_boff;
+            s.off0 = (unsigned)min((ur0 >> 6) * GM + add + (ur0 & 63), lim) * a_rb + cs0;
+            s.off1 = (unsigned)min((ur1 >> 6) * GM + add + (ur1 & 63), lim) * a_rb + cs1;
         } else {  // W rows: wave column (ur>>5) * 64 + (unit 2 ? 32 : 0) + (ur & 31)
             const int lim = n_valid - tni * 256 - 1;
             const int add = unit == 2 ? 32 : 0;
@@ -603,7 +613,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
     // for them they sit in the XCD's L2.  Measured (profiles/r1_v4_*): fc2 (80 K tiles per tile) -3 %,
     // out_proj (20 K tiles) +7 % because its epilogue burst is HBM-bandwidth bound, so it is only used for
     // long K loops.  (DBG bit 7 switches it off for A/B runs.)
-    constexpr bool XPF = (EPI == EPI_RESID_F32) && !(DBG & 128);
+    constexpr bool XPF = (EPI == EPI_RESID_F32) && !(DBG & 128) && !HM;
     unsigned x_dummy = 0;  // destination of those loads; never read
     int m_base_cur = 0, n_base_cur = 0;
     bool last_kt = false;
@@ -646,10 +656,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
             quad(acc[1][0], acc[1][1], fw1, fa);
             wg_barrier();
             // ---- phase 2 -----------------------------------------------------------------------
-            rdA(fa, sb + 3 * P_UNIT);
+            if constexpr (!HM) rdA(fa, sb + 3 * P_UNIT);
             issue(sA0, 0, cur);
             wg_barrier();
-            quad(acc[1][2], acc[1][3], fw1, fa);
+            if constexpr (!HM) quad(acc[1][2], acc[1][3], fw1, fa);
             wg_barrier();
             // ---- phase 3 -----------------------------------------------------------------------
             issue(sW0, 1, cur);
@@ -659,7 +669,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
             if constexpr (XPF)
                 if (last_kt && nk >= 40) prefetch_x();  // after the K tile's last counted wait
             wg_barrier();
-            quad(acc[0][2], acc[0][3], fw0, fa);
+            if constexpr (!HM) quad(acc[0][2], acc[0][3], fw0, fa);
             wg_barrier();
         } else {
             // fa = (i0,i1) fragments of this position, read in L3 of the previous position
@@ -707,7 +717,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
         tile_coords(it, tmi, tni, bz);
         const int zo = bz / binner, zi = bz - zo * binner;
         const size_t out_off = GEN ? (size_t)(zo * p.o_bo + zi * p.o_bi) : 0;
-        const int m_base = tmi * 256 + grp * 128, n_base = tni * 256 + wn * 64;
+        const int m_base = tmi * TM + grp * GM, n_base = tni * 256 + wn * 64;
         init_acc(n_base);
         stamp(it, 0);
 
@@ -730,11 +740,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
 #pragma unroll
                 for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[j][i]));
         } else {
-            bool full = (m_base + 128 <= p.M) && (n_base + 64 <= p.N);
+            bool full = (m_base + GM <= p.M) && (n_base + 64 <= p.N);
             if constexpr (EPI == EPI_V_T) full = full && (p.T % 32 == 0);
-            if (full) epilogue8<T, EPI, true, (DBG & 16) != 0, GEN>(p, acc, m_base, n_base, lane, slice, out_off, zo, zi);
-            else epilogue8<T, EPI, false, (DBG & 16) != 0, GEN>(p, acc, m_base, n_base, lane, slice, out_off, zo, zi);
-            young_stores = full && !(DBG & 16);
+            constexpr int NI = HM ? 2 : 4;
+            if (full) epilogue8<T, EPI, true, (DBG & 16) != 0, GEN, NI>(p, acc, m_base, n_base, lane, slice, out_off, zo, zi);
+            else epilogue8<T, EPI, false, (DBG & 16) != 0, GEN, NI>(p, acc, m_base, n_base, lane, slice, out_off, zo, zi);
+            young_stores = full && !(DBG & 16) && !HM;
         }
         if constexpr (XPF) asm volatile("" : "+v"(x_dummy));  // the epilogue's own loads retired them
         stamp(it, 2);
@@ -751,6 +762,27 @@ bool gemm8_generalised(const GemmArgs& p, int epi) {
     return p.a_row_bytes || p.w_row_bytes || p.a_kt_bytes || p.w_kt_bytes || p.batch > 1 || p.n_valid > 0 ||
            p.ldc > 0 || p.row_keep != nullptr || p.vt_rows > 0 || p.rowmap_R > 0 || epi == EPI_MSA_CTX ||
            p.head_dim != 64 || p.row_pos != nullptr;
+}
+
+static int num_workgroups();
+
+// Half-height tiles (gemm8_kernel<..., HM>) cost 0.7 - 0.95 of a full tile each (tools/bench_half_tiles.py,
+// profiles/r2_half_height_tiles.log: the K loop of a tile is bound by operand delivery into the LDS, and a half tile
+// still stages the whole W slab), so they only pay when BOTH tile heights fit in the same number of rounds over the
+// CUs, i.e. when 256-row tiles leave CUs idle (B <= 4 sequences of 1024 tokens at N = 1280).  ESMK_GEMM8_HM = 0 / 1
+// forces.
+constexpr double HM_TILE_COST = 0.8;
+bool gemm8_half_height(const GemmArgs& p) {
+    if (p.half_m != 0) return p.half_m > 0;
+    static const int env = [] {
+        const char* e = getenv("ESMK_GEMM8_HM");
+        return e ? atoi(e) : -1;
+    }();
+    if (env >= 0) return env != 0;
+    const long long wg = num_workgroups(), tn = (p.N + 255) / 256;
+    const long long t256 = (long long)((p.M + 255) / 256) * tn, t128 = (long long)((p.M + 127) / 128) * tn;
+    const double full = (double)((t256 + wg - 1) / wg), half = HM_TILE_COST * (double)((t128 + wg - 1) / wg);
+    return half < 0.97 * full;
 }
 
 static int num_workgroups() {
@@ -770,10 +802,10 @@ void gemm8_set_timing(unsigned long long* dev_buf) { g_timing = dev_buf; }
 
 constexpr int PF_DEFAULT = 0;
 
-template <typename T, int EPI, int SCHED = 0, int DBG = 0, int PF = PF_DEFAULT, bool GEN = false>
+template <typename T, int EPI, int SCHED = 0, int DBG = 0, int PF = PF_DEFAULT, bool GEN = false, bool HM = false>
 static hipError_t launch8(GemmArgs p, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = gemm8_kernel<T, EPI, SCHED, DBG, PF, GEN>;
+    auto kern = gemm8_kernel<T, EPI, SCHED, DBG, PF, GEN, HM>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
@@ -859,6 +891,17 @@ static hipError_t dispatch8(const GemmArgs& p, int epi, hipStream_t st) {
     if constexpr (std::is_same<T, _Float16>::value) {
         if (mode == 3) { ESMK_CASES(0, 32, 0) }
         if (mode == 4) { ESMK_CASES(0, 128, 0) }
+    }
+    if (gemm8_half_height(p)) {
+        switch (epi) {
+            case EPI_STORE_T: return launch8<T, EPI_STORE_T, 0, 0, 0, false, true>(p, st);
+            case EPI_STORE_F32: return launch8<T, EPI_STORE_F32, 0, 0, 0, false, true>(p, st);
+            case EPI_GELU_T: return launch8<T, EPI_GELU_T, 0, 0, 0, false, true>(p, st);
+            case EPI_GELU_F32: return launch8<T, EPI_GELU_F32, 0, 0, 0, false, true>(p, st);
+            case EPI_RESID_F32: return launch8<T, EPI_RESID_F32, 0, 0, 0, false, true>(p, st);
+            case EPI_QKV_ROPE: return launch8<T, EPI_QKV_ROPE, 0, 0, 0, false, true>(p, st);
+            case EPI_V_T: return launch8<T, EPI_V_T, 0, 0, 0, false, true>(p, st);
+        }
     }
     ESMK_CASES(0, 0, PF_DEFAULT)
 #undef ESMK_CASES

@@ -27,6 +27,7 @@ struct GemmArgs {
     int force_generic = 0;
     int force_old = 0;  // use the one-tile-per-workgroup kernels of gemm.hip (A/B measurements, tests)
     int panel_c = 0;    // gemm8: N tiles per column panel of the tile order (0 = choose)
+    int half_m = 0;     // gemm8: 128-row tiles: 0 = decide from the tile count, 1 = force, -1 = never (A/B, tests)
     int dbg = 0;  // timing experiments only (tools/microbench.py): 1 no staging, 2 no barrier, 4 no LDS reads
     // EPI_QKV_ROPE only
     void* q = nullptr;   // [B,H,T,64]
@@ -55,6 +56,7 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
 // gemm8.hip: persistent ping-pong kernel (K % 64 == 0, N % 8 == 0); launch_gemm prefers it
 bool gemm8_supports(const GemmArgs& p, int epi);
 bool gemm8_generalised(const GemmArgs& p, int epi);  // uses fields only the persistent kernel implements
+bool gemm8_half_height(const GemmArgs& p);            // dense kernels: 128 x 256 tiles for this shape?
 hipError_t launch_gemm8(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st);
 // measurement hook: per-tile s_memtime stamps of workgroup-leader lanes ([workgroup][tile & 31][4])
 void gemm8_set_timing(unsigned long long* dev_buf);

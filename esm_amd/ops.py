@@ -45,7 +45,7 @@ def masked_row_mean(x, counts, first_row=1):
 
 
 def linear(a, w, bias=None, epilogue=N.EPI_STORE_T, out=None, force_generic=False, dbg=0, force_old=False,
-           panel_c=0):
+           panel_c=0, half_m=0):
     """nn.Linear with fused epilogue: a [M,K], w [N,K] (both f16 or bf16), bias fp32 [N]."""
     _req_cuda(a, w, bias, out)
     assert a.dtype == w.dtype and a.dtype in (torch.float16, torch.bfloat16)
@@ -60,7 +60,7 @@ def linear(a, w, bias=None, epilogue=N.EPI_STORE_T, out=None, force_generic=Fals
     # 0x100: generic 64x64 kernel, 0x200: one-tile-per-workgroup 256x256 kernel (gemm.hip) instead of the
     # persistent kernel (gemm8.hip); bits 20..27: tile-order panel width of the persistent kernel
     code = (N.dtype_code(a.dtype) | (0x100 if force_generic else 0) | (0x200 if force_old else 0) | (dbg << 12)
-            | (panel_c << 20))
+            | (panel_c << 20) | ({0: 0, 1: 1, -1: 2}[half_m] << 28))  # half_m: 1 force 128-row tiles, -1 never
     N.check(N.lib.esmk_op_linear(N.ptr(a), N.ptr(w), N.ptr(bias), N.ptr(out), M, Nn, K, epilogue, code,
                                  N.cur_stream()))
     return out

@@ -124,6 +124,47 @@ def test_persistent_gemm_bit_exact_vs_tile_kernel(ops, M, N, K, dt):
     assert (acc_new - (resid + ref)).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 1280, 1280), (4096, 1280, 5120), (1100, 2560, 1280), (4224, 5120, 320), (100, 264, 64)])
+@pytest.mark.parametrize("dt", DT)
+def test_half_height_tiles_bit_exact(ops, M, N, K, dt):
+    """gemm8_kernel<..., HM>: 128 x 256 tiles for shapes that leave most CUs idle with 256-row tiles.  Every output
+    element sees the same MFMA sequence over K as in the full-height kernel, so the results are bit-identical —
+    whichever tile height the batch size selects (small-batch forwards must not differ from large-batch ones)."""
+    from esm_amd import _native as nat
+
+    g = torch.Generator(device="cuda").manual_seed(13)
+    a = torch.randn(M, K, device="cuda", generator=g).to(dt)
+    w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(dt)
+    bias = torch.randn(N, device="cuda", generator=g)
+    for epi in (nat.EPI_STORE_F32, nat.EPI_GELU_T, nat.EPI_STORE_T, nat.EPI_GELU_F32):
+        full = ops.linear(a, w, bias, epi, half_m=-1)
+        for rep in range(2):
+            half = ops.linear(a, w, bias, epi, half_m=1, panel_c=(0, 2)[rep])
+            assert torch.equal(half, full), (epi, rep, (half.float() - full.float()).abs().max().item())
+    resid = torch.randn(M, N, device="cuda", generator=g)
+    x_full, x_half = resid.clone(), resid.clone()
+    ops.linear(a, w, bias, nat.EPI_RESID_F32, out=x_full, half_m=-1)
+    ops.linear(a, w, bias, nat.EPI_RESID_F32, out=x_half, half_m=1)
+    assert torch.equal(x_half, x_full)
+
+
+def test_small_batch_forward_equals_large_batch_rows():
+    """B = 2 (half-height GEMM tiles, chosen from the tile count) and B = 16 (full-height): the same sequence gives
+    the same bits in both batches."""
+    import esm
+    from esm_amd.synth import synth_esm2_state_dict, synth_tokens
+
+    L, E, H = 2, 1280, 20
+    model = esm.ESM2(L, E, H).eval().requires_grad_(False)
+    model.load_state_dict(synth_esm2_state_dict(L, E, H, seed=3))
+    model = model.cuda()
+    toks = synth_tokens(16, 1022, seed=5).cuda()
+    big = model(toks, repr_layers=[L])
+    small = model(toks[:2], repr_layers=[L])
+    assert torch.equal(small["representations"][L], big["representations"][L][:2])
+    assert torch.equal(small["logits"], big["logits"][:2])
+
+
 def _rope_ref(x, inv_freq):
     # reference esm/rotary_embedding.py:11-20,47-61 restated for [B,H,T,d]
     T = x.shape[-2]
