@@ -76,7 +76,9 @@ constexpr float LAZY_LIMIT = 4096.f;
 // t-1 issued in one basic block with the exponentials of tile t; 200+ VGPRs -> 2 waves per SIMD): 15.5 vs 13.1 ms
 // per step.  The PMC pass shows why: VALU-port time (711 cycles per wave and tile) plus matrix-pipe time (512)
 // add up to the kernel's duration — the limiter is how well the hardware interleaves the waves of a SIMD, which a
-// third resident wave helps more than in-wave scheduling.
+// third resident wave helps more than in-wave scheduling.  Also measured and dropped: the row sum as 16 v_dot2c_f32_f16
+// against (1, 1) on the packed P instead of 32 v_add_f32 (481-487 vs 478.6 us on the micro-benchmark: a dot2c costs more
+// than the two adds it replaces).
 template <typename T, int LAZY>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
