@@ -117,6 +117,22 @@ def live_tensors(engine, model, skip):
     return [(key, store[name]) for key, store, name in engine._named]
 
 
+def check_finite(result):
+    """``ESM_AMD_CHECK_FINITE=1`` (debug aid, synchronises): raise if an output holds inf / NaN.  The engine rounds
+    GEMM operands to fp16 (range 65504) also for fp32 models; this has been validated on seeded synthetic weights
+    only (no released checkpoint is available offline), so a first run on real weights can be checked this way.
+    Pad positions are included: the reference leaves finite garbage there as well."""
+    if os.environ.get("ESM_AMD_CHECK_FINITE", "0") != "1":
+        return
+    def walk(prefix, v):
+        if isinstance(v, dict):
+            for k, t in v.items():
+                walk(f"{prefix}[{k!r}]", t)
+        elif torch.is_tensor(v) and v.is_floating_point() and not bool(torch.isfinite(v).all()):
+            raise FloatingPointError(f"esm_amd: {prefix} contains inf / NaN (fp16 operand overflow? try ESM_AMD_OPERAND=bf16)")
+    walk("out", result)
+
+
 def warn_if_grad_expected(model):
     """The engine is forward-only: outputs carry no grad_fn.  The reference's own tests call forward without
     ``no_grad`` (tests/test_load_all.py:39-47), so this warns — once per model — instead of raising."""
@@ -325,12 +341,15 @@ class ESM2(nn.Module):
         out_dt = w.dtype
         cast = lambda t: t if t.dtype == out_dt else t.to(out_dt)
         if contacts_only:
-            return {"contacts": cast(contacts), "representations": {l: cast(r) for l, r in zip(repr_set, reps)}}
+            result = {"contacts": cast(contacts), "representations": {l: cast(r) for l, r in zip(repr_set, reps)}}
+            check_finite(result)
+            return result
         result = {"logits": cast(logits), "representations": {l: cast(r) for l, r in zip(repr_set, reps)}}
         if need_head_weights:
             result["attentions"] = cast(attn)
             if return_contacts:
                 result["contacts"] = cast(contacts)
+        check_finite(result)
         return result
 
     # ------------------------------------------------------------------------------------------
