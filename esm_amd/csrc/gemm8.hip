@@ -613,7 +613,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
     // for them they sit in the XCD's L2.  Measured (profiles/r1_v4_*): fc2 (80 K tiles per tile) -3 %,
     // out_proj (20 K tiles) +7 % because its epilogue burst is HBM-bandwidth bound, so it is only used for
     // long K loops.  (DBG bit 7 switches it off for A/B runs.)
-    constexpr bool XPF = (EPI == EPI_RESID_F32) && !(DBG & 128) && !HM;
+    constexpr bool XPF = (EPI == EPI_RESID_F32) && !(DBG & 128);
     unsigned x_dummy = 0;  // destination of those loads; never read
     int m_base_cur = 0, n_base_cur = 0;
     bool last_kt = false;
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
         if constexpr (XPF) {
             const float* xo_ = reinterpret_cast<const float*>(p.out);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < (HM ? 2 : 4); ++q) {  // 2 cache lines per row of the wave's 128 (HM: 64) rows
                 const int L = q * 64 + lane;
                 const int row = min(m_base_cur + (L >> 1), p.M - 1);
                 const int n = min(n_base_cur + (L & 1) * 32, p.N - 4);
