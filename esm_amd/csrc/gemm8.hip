@@ -767,8 +767,8 @@ bool gemm8_generalised(const GemmArgs& p, int epi) {
 static int num_workgroups();
 
 // Half-height tiles (gemm8_kernel<..., HM>) cost 0.7 - 0.95 of a full tile each (tools/bench_half_tiles.py,
-// profiles/r2_half_height_tiles.log: the K loop of a tile is bound by operand delivery into the LDS, and a half tile
-// still stages the whole W slab), so they only pay when BOTH tile heights fit in the same number of rounds over the
+// profiles/r2_half_height_tiles.log: with half the MFMAs the K step lands on the loop's ~1700-cycle non-MFMA
+// skeleton — DMA landing, fragment reads, barriers — instead of 1041 cycles of MFMA issue), so they only pay when BOTH tile heights fit in the same number of rounds over the
 // CUs, i.e. when 256-row tiles leave CUs idle (B <= 4 sequences of 1024 tokens at N = 1280).  ESMK_GEMM8_HM = 0 / 1
 // forces.
 constexpr double HM_TILE_COST = 0.8;
