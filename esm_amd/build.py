@@ -86,6 +86,11 @@ def build(force=False, verbose=True):
     subprocess.check_call(cmd)
     if library_hash() != srchash:
         raise RuntimeError("libesmk.so does not carry the hash of the sources it was just built from")
+    # every kernel the host code launches must have been emitted (an uninstantiable template leaves an undefined
+    # __device_stub__ symbol that only shows up at dlopen time)
+    import ctypes
+
+    ctypes.CDLL(LIB)
     return LIB
 
 

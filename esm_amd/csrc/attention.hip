@@ -78,8 +78,9 @@ constexpr float LAZY_LIMIT = 4096.f;
 // add up to the kernel's duration — the limiter is how well the hardware interleaves the waves of a SIMD, which a
 // third resident wave helps more than in-wave scheduling.  Also measured and dropped: the row sum as 16 v_dot2c_f32_f16
 // against (1, 1) on the packed P instead of 32 v_add_f32 (481-487 vs 478.6 us on the micro-benchmark: a dot2c costs more
-// than the two adds it replaces).
-template <typename T, int LAZY>
+// than the two adds it replaces); unrolling the key-tile loop by two so that the LDS buffer is a compile-time constant
+// (fragment addresses as lane base + immediate): 332 bytes of scratch at the 168-VGPR budget of 3 waves per SIMD.
+template <typename T, int LAZY, bool BUF = true>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
     const float* __restrict__ key_bias, const int* __restrict__ seq_info, T* __restrict__ ctx,
@@ -155,20 +156,43 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qp + 16 * ks);
     }
 
-    // staging sources: 2 rounds of 256 lanes each for K and for V^T.  Lane tid copies 16-byte chunk c of row
-    // r0 (round 0) and of row r0 + 32 (round 1): the swizzle (r >> 1) & 7 is the same for both rows, so one
-    // 32-bit element offset per stream is all that is kept in registers.
+    // Staging: 2 rounds of 256 lanes each for K and for V^T; lane tid copies 16-byte chunk c of row r0 (round 0)
+    // and of row r0 + 32 (round 1) — the swizzle (r >> 1) & 7 is the same for both rows.  The copies are
+    // buffer_load ... lds with the per-lane byte offset FIXED and the tile advance in the scalar offset: the whole
+    // per-tile address arithmetic is one s_mul on the scalar unit (instruction issue, not the matrix pipe, bounds this
+    // kernel — DESIGN.md §4.2 — and the global_load_lds form cost ~14 VALU instructions per tile for 64-bit
+    // addresses and row clamps).  K rows past the end of the sequence / segment are out of range of the K
+    // descriptor and arrive as zeros (they are masked: use_mask is set whenever the length is not a multiple of 64).
     const int r0 = tid >> 3;
     const int kcol = ((tid & 7) ^ ((r0 >> 1) & 7)) * 8;  // element offset of the chunk inside a 64-element row
-    const int voff = r0 * Tp + kcol;                      // V^T: row r0 (a dv), chunk c of the tile's 64 keys
+    const unsigned kvo0 = (unsigned)(r0 * 64 + kcol) * (unsigned)sizeof(T), kvo1 = kvo0 + 32u * 128u;
+    const unsigned vvo0 = (unsigned)(r0 * Tp + kcol) * (unsigned)sizeof(T), vvo1 = vvo0 + 32u * (unsigned)Tp * (unsigned)sizeof(T);
+    auto uniform_ptr = [](const void* p) {  // provably wave-uniform for the compiler: no waterfall loop around the loads
+        const unsigned long long a = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return (void*)(((unsigned long long)hi << 32) | lo);
+    };
+    const __amdgpu_buffer_rsrc_t kdesc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(kb), 0, __builtin_amdgcn_readfirstlane(Tseg * 128), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vdesc = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(vb), 0, __builtin_amdgcn_readfirstlane((int)(((size_t)64 * Tp - (size_t)row0) * sizeof(T) > 0x7fffffffu
+                                                                     ? 0x7fffffff : (int)(((size_t)64 * Tp - (size_t)row0) * sizeof(T)))), 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * A_STAGE;
         const int k0 = kt * 64;
+        const unsigned sk_off = (unsigned)kt * 8192u, sv_off = (unsigned)kt * 128u;
+        if constexpr (BUF) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(kdesc, (lds_ptr)(base + (wave * 64) * 16), 16, kvo0, sk_off, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vdesc, (lds_ptr)(base + A_TILE + (wave * 64) * 16), 16, vvo0, sv_off, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(kdesc, (lds_ptr)(base + (256 + wave * 64) * 16), 16, kvo1, sk_off, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vdesc, (lds_ptr)(base + A_TILE + (256 + wave * 64) * 16), 16, vvo1, sv_off, 0, 0);
+        } else {  // round-1 form (A/B: ESMK_ATTN bit 3): global_load_lds with per-lane 64-bit addresses, rows clamped
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int kr = min(k0 + r0 + 32 * j, Tseg - 1);
-            glds16(kb + (size_t)kr * 64 + kcol, base + (j * 256 + wave * 64) * 16);
-            glds16(vb + (size_t)(voff + 32 * j * Tp) + k0, base + A_TILE + (j * 256 + wave * 64) * 16);
+            for (int j = 0; j < 2; ++j) {
+                const int kr = min(k0 + r0 + 32 * j, Tseg - 1);
+                glds16(kb + (size_t)kr * 64 + kcol, base + (j * 256 + wave * 64) * 16);
+                glds16(vb + (size_t)(r0 * Tp + kcol + 32 * j * Tp) + k0, base + A_TILE + (j * 256 + wave * 64) * 16);
+            }
         }
         if (use_mask && tid < 64) {
             const int key = k0 + tid;
@@ -390,20 +414,21 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
     const int nq = segs.work != nullptr ? n_items : (T + 127) / 128;
     dim3 grid(nq * B * H);
     // ESMK_ATTN (read once): bit 0 XCD-grouped grid (default on), bit 1 = textbook online softmax instead of the
-    // lazy-offset one (A/B measurements; both are exact softmax)
+    // lazy-offset one, bit 3 = round-1 staging by global_load_lds (A/B measurements; all are exact softmax)
     static const int var = [] {
         const char* e = getenv("ESMK_ATTN");
         return e ? atoi(e) : ATTN_DEFAULT_VARIANT;
     }();
-#define ESMK_ATTN_LAUNCH(TT, LZ)                                                                      \
-    hipLaunchKernelGGL((attn_fwd_kernel<TT, LZ>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k,   \
+#define ESMK_ATTN_LAUNCH(TT, LZ, BF)                                                                      \
+    hipLaunchKernelGGL((attn_fwd_kernel<TT, LZ, BF>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k,   \
                        (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad, segs)
     if (operand_dtype == ESMK_DT_BF16) {
-        if (var & 2) ESMK_ATTN_LAUNCH(__bf16, 0);
-        else ESMK_ATTN_LAUNCH(__bf16, 1);
+        if (var & 2) ESMK_ATTN_LAUNCH(__bf16, 0, true);
+        else ESMK_ATTN_LAUNCH(__bf16, 1, true);
     } else {
-        if (var & 2) ESMK_ATTN_LAUNCH(_Float16, 0);
-        else ESMK_ATTN_LAUNCH(_Float16, 1);
+        if (var & 2) ESMK_ATTN_LAUNCH(_Float16, 0, true);
+        else if (var & 8) ESMK_ATTN_LAUNCH(_Float16, 1, false);
+        else ESMK_ATTN_LAUNCH(_Float16, 1, true);
     }
 #undef ESMK_ATTN_LAUNCH
     return hipGetLastError();
