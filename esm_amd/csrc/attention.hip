@@ -47,7 +47,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 // XCD-grouped grid 16.14 (kept), three LDS stages 17.45, split reductions 16.64 (both removed)
 constexpr int ATTN_DEFAULT_VARIANT = 1;
 constexpr int A_TILE = 64 * 128;  // bytes of one K (or V^T) tile: 64 rows x 128 B
-constexpr int A_STAGE = 2 * A_TILE + 256;  // K + V^T + 64 fp32 key-bias values
+constexpr int A_STAGE = 2 * A_TILE + 256 + 16;  // K + V^T + 64 fp32 key-bias values + "tile has a masked key" flag
 
 ESMK_DEV void attn_barrier() {
     __builtin_amdgcn_sched_barrier(0);
@@ -203,6 +203,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
                 if (fill_mode) bv = (bv != 0.f) ? INFINITY : 0.f;
             }
             reinterpret_cast<float*>(base + 2 * A_TILE)[tid] = bv;
+            // Only tiles that contain a masked key (the tail of the row, <pad> tokens, fill flags) pay for the mask:
+            // adding the 0.0 bias of an unmasked key leaves every score bit for bit unchanged, so skipping the whole
+            // 80-instruction mask block on clean tiles changes nothing but the issue time.  tid < 64 is all of wave 0.
+            const bool any_masked = __builtin_amdgcn_ballot_w64(bv != 0.f) != 0;
+            if (tid == 0) *reinterpret_cast<int*>(base + 2 * A_TILE + 256) = any_masked ? 1 : 0;
         }
     };
 
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
             }
         }
         // ---- key padding / tail mask (multihead_attention.py:368-374) -----------------------
-        if (use_mask) {
+        if (use_mask && __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(sk + 2 * A_TILE + 256)) != 0) {
             const float fillv = -10000.f * LOG2E - (LAZY ? m_off : 0.f);  // masked_fill(-10000), same domain as st
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
@@ -328,10 +333,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
                         pf[2 * t2 + ks][e] = Op<T>::from(p);
                     }
             lsum = lsum * alpha + ps;
+            // the first tile of every row (alpha = 1 by definition) and exact tiles in which no row's offset moved
+            // skip the 32 multiplies: multiplying by 1.0 changes no bit
+            if (!LAZY || __builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
 #pragma unroll
-            for (int d = 0; d < 2; ++d)
+                for (int d = 0; d < 2; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            }
             if constexpr (LAZY) {
                 m_off += delta;
 #pragma unroll
