@@ -79,7 +79,10 @@ constexpr float LAZY_LIMIT = 4096.f;
 // third resident wave helps more than in-wave scheduling.  Also measured and dropped: the row sum as 16 v_dot2c_f32_f16
 // against (1, 1) on the packed P instead of 32 v_add_f32 (481-487 vs 478.6 us on the micro-benchmark: a dot2c costs more
 // than the two adds it replaces); unrolling the key-tile loop by two so that the LDS buffer is a compile-time constant
-// (fragment addresses as lane base + immediate): 332 bytes of scratch at the 168-VGPR budget of 3 waves per SIMD.
+// (fragment addresses as lane base + immediate): 332 bytes of scratch at the 168-VGPR budget of 3 waves per SIMD; the
+// row sum on the matrix pipe (4 MFMAs of an all-ones A operand with the P fragments, Q re-read from an LDS image to free
+// the accumulator's 16 registers; exact, 168 VGPRs): 511 vs 452 us — the wave has to read the MFMA result back for the
+// overflow check before P.V may start, and that dependency costs more than the 32 adds.
 template <typename T, int LAZY, bool BUF = true>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
