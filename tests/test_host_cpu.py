@@ -144,6 +144,32 @@ def test_c_abi_exports_every_declared_symbol():
     assert b"gfx950" in _native.lib.esmk_version()
 
 
+def test_library_carries_the_hash_of_its_sources():
+    """esmk_version() ends in the SHA-256 prefix of the sources the .so was compiled from (esm_amd/build.py); the
+    build is gated on it (not on mtimes) and bench.py uses it to decide whether the committed PMC traffic numbers
+    belong to the running binary."""
+    from esm_amd import build
+
+    version = _native.lib.esmk_version().decode()
+    assert version.endswith("esmk-src:" + build.source_hash()), (version, build.source_hash())
+    assert build.library_hash() == build.source_hash() and not build.needs_build()
+
+
+def test_self_launch_helpers():
+    from esm_amd import launch
+
+    p = launch.free_port()
+    assert 1024 < p < 65536
+    env = {k: os.environ.pop(k) for k in ("RANK", "WORLD_SIZE") if k in os.environ}
+    try:
+        assert not launch.under_launcher()
+        assert launch.init_ranks(1, "gloo") == (None, 0, 1, 0)  # no launcher, one rank: no process group
+        with pytest.raises(SystemExit):
+            launch.init_ranks(2, "gloo")                         # asked for 2 ranks, launched as 1
+    finally:
+        os.environ.update(env)
+
+
 def test_pack_plan_layout():
     """Host side of token-packed batches (esm_amd/packing.py): segment starts on multiples of 16, the row count a
     multiple of 128, pack / unpack are inverse on the non-pad positions."""
