@@ -150,10 +150,18 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
     const T* kb = k + rbase * 64;
     const T* vb = vt + (size_t)bh * 64 * Tp + row0;
 
-    // Q fragments: Q[q0 + lm][16 ks + 8 h .. +7]
+    // Query rows at or past kv_end are padding (right-padded batch; kv_end = Tseg otherwise).  They take the last
+    // real row's place in their wave — exactly what a wave's surplus lanes do when the sequence runs alone or
+    // token-packed — and waves made of padding only do no work and write zeros.  The lazy softmax takes its
+    // exact / fast decision per WAVE, so a row's bits depend on its wave mates: with this rule the mates are the
+    // same in a padded batch, alone and packed, and the three layouts stay bit-identical on every real row
+    // (tools/fuzz_attention_lengths.py).  The reference computes garbage on padded query rows; every caller drops it.
+    const int q_end = max(kv_end, 1);
+    const bool wave_active = q0 < q_end && kv_end > 0;  // wave uniform
+    // Q fragments: Q[min(q0 + lm, q_end - 1)][16 ks + 8 h .. +7]
     V8 qf[4];
     {
-        const int qr = min(q0 + lm, Tseg - 1);
+        const int qr = min(q0 + lm, q_end - 1);
         const T* qp = q + (rbase + qr) * 64 + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qp + 16 * ks);
@@ -245,6 +253,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
         cur ^= 1;
         const char* sv = sk + A_TILE;
         const float* sb = reinterpret_cast<const float*>(sk + 2 * A_TILE);
+        if (wave_active) {
 
         // ---- S^T = K . Q^T (- m_off) for 64 keys (two 32-key tiles) ---------------------------
         f32x16 st[2];
@@ -358,13 +367,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
                 const V8 vf = *reinterpret_cast<const V8*>(sv + d * 4096 + lrow + xo[kk]);
                 o[d] = Op<T>::mma(vf, pf[kk], o[d]);
             }
+        }  // wave_active
         wait_vmcnt0();
         __syncthreads();
     }
 
     // ---- normalise and store ctx[b*T + q][head*64 + dv] ---------------------------------------
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
-    const float inv = 1.0f / ltot;
+    const float inv = wave_active ? 1.0f / ltot : 0.f;  // padding-only waves: O^T is still zero
     // Stage the wave's [32 queries][64 dv] block through its private 4 KiB LDS slice (all waves
     // have passed the last barrier, the K/V buffers are dead) so that the global stores are 16 B
     // per lane and cover whole 128-byte rows instead of 8-byte pieces of 32 different rows.
@@ -389,7 +399,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
     }
     // log-sum-exp of the row in the log2 domain (the map kernels compute exp2(s - lse2))
     const int qrow = q0 + lm;
-    if (lse != nullptr && h == 0 && qrow < Tseg) lse[rbase + qrow] = m_off + log2f(ltot);
+    if (lse != nullptr && h == 0 && qrow < Tseg) lse[rbase + qrow] = wave_active ? m_off + log2f(ltot) : 0.f;
 }
 
 static hipError_t launch_attention_impl(const void* q, const void* k, const void* vt, const float* key_bias,

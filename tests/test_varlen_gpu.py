@@ -171,3 +171,18 @@ def test_packed_esm1b(ln_before):
             for layer in (0, L):
                 assert torch.equal(out["representations"][layer][b, :n], one["representations"][layer][0]), (b, n, layer)
             assert torch.equal(out["logits"][b, :n], one["logits"][0]), (b, n)
+
+
+def test_random_lengths_padded_packed_alone_bit_equal():
+    """Random batches of random lengths (tools/fuzz_attention_lengths.py, 650M width): the padded forward, the
+    token-packed forward and each sequence alone agree bit for bit on every real row.  The lazy softmax takes its
+    exact / fast decision per wave, so this also pins the rule that padded query rows mirror the last real row of
+    their wave (attention.hip) — a first version without it differed by 6e-4 on a (963, 713) batch."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_attention_lengths.py")
+    spec = importlib.util.spec_from_file_location("fuzz_attention_lengths", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(["--iters", "16", "--seed", "3"])
