@@ -39,7 +39,14 @@ def main():
             ref = ref + res
         if epi in (nat.EPI_GELU_T, nat.EPI_GELU_F32):
             ref = gelu(ref)
-        got = ops.linear(x, w, bias, epi, out=out, panel_c=ri(0, 6))
+        hm = (0, 1, -1)[ri(0, 2)]  # tile height: decided from the tile count / forced 128 rows / forced 256 rows
+        got = ops.linear(x, w, bias, epi, out=out, panel_c=ri(0, 6), half_m=hm)
+        if hm != 0:  # the two tile heights must agree bit for bit (same MFMA sequence over K per element)
+            out2 = res.clone() if epi == nat.EPI_RESID_F32 else None
+            other = ops.linear(x, w, bias, epi, out=out2, half_m=-hm)
+            if not torch.equal(other, got):
+                print(f"FAIL case {case}: half / full tile heights differ: M={M} N={N} K={K} epi={epi} dt={dt}")
+                sys.exit(1)
         eps = 2.0 ** -11 if dt == torch.float16 else 2.0 ** -8
         tol = 1e-4 * math.sqrt(K) + (eps * ref.abs().max().item() if got.dtype != torch.float32 else 0) + 1e-5
         err = (got.float() - ref).abs().max().item()
