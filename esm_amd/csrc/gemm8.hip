@@ -667,7 +667,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
             if constexpr (PF > 0) asm volatile("" : "+v"(pf_dummy));  // the previous prefetch has retired
             prefetch();
             if constexpr (XPF)
-                if (last_kt && nk >= 40) prefetch_x();  // after the K tile's last counted wait
+                if (last_kt) prefetch_x();  // after the K tile's last counted wait (last_kt: the K tile chosen for it)
             wg_barrier();
             if constexpr (!HM) quad(acc[0][2], acc[0][3], fw0, fa);
             wg_barrier();
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
         n_base_cur = n_base;
 #pragma unroll 1
         for (int kt = 0; kt < nk; ++kt) {
-            last_kt = (kt == nk - 1);
+            last_kt = (kt == p.xpf_kt);  // K tile after which the residual tile is prefetched (-1: never)
             ktile();
             young_stores = false;
         }
@@ -825,6 +825,21 @@ static hipError_t launch8(GemmArgs p, hipStream_t st) {
         else if (tiles_n % 4 == 0) p.panel_c = 4;
         else if (tiles_n % 6 == 0) p.panel_c = 6;
         else p.panel_c = 5;
+    }
+    {   // EPI_RESID_F32: K tile after which each wave touches its residual lines (see prefetch_x).  The prefetch pays
+        // when a workgroup has ONE tile (small batches: nothing else hides the epilogue's residual loads — fc2 at B = 4:
+        // 4.26 -> 3.38 ms per forward) and costs when every workgroup walks several tiles and the chip is bandwidth /
+        // power bound (B = 64, round 2, one call: fc2 26.2 -> 25.3 ms per step without it, out_proj 8.75 -> 9.7-10.0 with
+        // it), so it is used for single-round launches with a long K loop only.
+        // ESMK_XPF_D / ESMK_XPF_MIN_NK / ESMK_XPF_ROUNDS (experiments): distance from the end of the K loop, shortest K
+        // loop, most tile rounds it is used for.
+        static const int xd = [] { const char* e = getenv("ESMK_XPF_D"); return e ? atoi(e) : 1; }();
+        static const int xmin = [] { const char* e = getenv("ESMK_XPF_MIN_NK"); return e ? atoi(e) : 40; }();
+        static const int xrounds = [] { const char* e = getenv("ESMK_XPF_ROUNDS"); return e ? atoi(e) : 1; }();
+        const int nk = p.K / 64, wg = num_workgroups();
+        const long long tiles = (long long)((p.M + (HM ? 127 : 255)) / (HM ? 128 : 256)) * ((p.N + 255) / 256) * (p.batch > 0 ? p.batch : 1);
+        const bool few = (tiles + wg - 1) / wg <= xrounds;
+        p.xpf_kt = (few && nk >= xmin && xd > 0) ? (nk - xd > 0 ? nk - xd : 0) : -1;
     }
     hipLaunchKernelGGL(kern, dim3(num_workgroups()), dim3(512), P_LDS, st, p, g_timing);
     return hipGetLastError();

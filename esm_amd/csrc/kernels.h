@@ -28,6 +28,7 @@ struct GemmArgs {
     int force_old = 0;  // use the one-tile-per-workgroup kernels of gemm.hip (A/B measurements, tests)
     int panel_c = 0;    // gemm8: N tiles per column panel of the tile order (0 = choose)
     int half_m = 0;     // gemm8: 128-row tiles: 0 = decide from the tile count, 1 = force, -1 = never (A/B, tests)
+    int xpf_kt = -1;    // gemm8, EPI_RESID_F32: K tile after which the residual tile is prefetched into the L2 (set by the launcher)
     int dbg = 0;  // timing experiments only (tools/microbench.py): 1 no staging, 2 no barrier, 4 no LDS reads
     // EPI_QKV_ROPE only
     void* q = nullptr;   // [B,H,T,64]
