@@ -247,3 +247,25 @@ def test_extract_embed_fn_dispatch():
     make_embed_fn(Plain())(toks, [1], True)
     assert calls == [("varlen", (3,), [5, 4]), ("forward", (3,), False, True), ("forward", (3,), False, False),
                      ("plain", (1,), True)]
+
+
+def test_gelu_polynomial_of_the_epilogues_matches_erf():
+    """The GEMM epilogues evaluate GELU as x (0.5 + u Q(t)) with the coefficients listed in csrc/common.h; replay that
+    evaluation in emulated fp32 (one rounding per FMA) and hold it against float64 erf (reference esm/modules.py:17-24).
+    Bound: 2e-6 absolute inside the clamp, 2e-6 |x| beyond — two orders below the fp16 rounding of the stored value."""
+    import sys
+
+    import numpy as np
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import fit_gelu_poly as fg
+
+    src = open(os.path.join(root, "esm_amd", "csrc", "common.h")).read()
+    body = re.search(r"#define ESMK_GELU_COEF\s*\\\s*\{(.*?)\}", src, re.S).group(1).replace("\\", " ")
+    coef = np.array([float(v.rstrip("f")) for v in body.replace("\n", " ").split(",")], dtype=np.float32)
+    clamp = float(re.search(r"kGeluClamp = ([0-9.]+)f", src).group(1))
+    k2 = float(re.search(r"kGeluK2 = ([0-9.e+-]+)f", src).group(1))
+    assert coef.size == 12 and np.float32(k2) == np.float32(2 / clamp**2)
+    e_in, e_out = fg.report(coef, clamp)
+    assert e_in < 2e-6 and e_out < 2e-6, (e_in, e_out)
