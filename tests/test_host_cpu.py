@@ -269,3 +269,31 @@ def test_gelu_polynomial_of_the_epilogues_matches_erf():
     assert coef.size == 12 and np.float32(k2) == np.float32(2 / clamp**2)
     e_in, e_out = fg.report(coef, clamp)
     assert e_in < 2e-6 and e_out < 2e-6, (e_in, e_out)
+
+
+def test_precision_study_tool_floor_is_ordered():
+    """tools/esm2_precision_study.py: the emulated fp16-operand forward differs from the fp32 one by the
+    order of the operand precision, bf16 is ~8x worse than fp16, and no injection at all is exact."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import esm2_precision_study as ps
+    from esm_amd.synth import synth_tokens
+
+    L, E, H = 3, 128, 2
+    sd = {k: v.float() for k, v in synth_esm2_state_dict(L, E, H, seed=5).items()}
+    toks = synth_tokens(2, 40, seed=6)
+    every = ("W", "A", "QK", "V", "P")
+    with torch.no_grad():
+        ref = ps.forward(sd, toks, L, H, (), torch.float16)
+        assert torch.equal(ref, ps.forward(sd, toks, L, H, (), torch.bfloat16))
+        rel = lambda t: ((t - ref).norm() / ref.norm()).item()
+        f16, bf16 = rel(ps.forward(sd, toks, L, H, every, torch.float16)), rel(ps.forward(sd, toks, L, H, every, torch.bfloat16))
+        w_only = rel(ps.forward(sd, toks, L, H, ("W",), torch.float16))
+    assert 5e-5 < f16 < 2e-3 and 4 < bf16 / f16 < 16 and w_only < f16
+    # and it is the oracle's forward: same result as oracle.esm2_oracle on the same inputs
+    from oracle.esm2_oracle import esm2_forward
+
+    want = esm2_forward(sd, toks, L, H, repr_layers=[L])["representations"][L]
+    assert (ref - want).abs().max().item() < 1e-5
