@@ -61,21 +61,35 @@ def argmax_report(logits, ref_logits):
             "argmax_agreement_where_decided": same[decided].float().mean().item() if bool(decided.any()) else None}
 
 
+PER_RANK_MS = []  # each rank's own ms per step of the last timed region (before it waits for the others)
+
+
 def timed_steps(step, steps, warmup, sync_all, dist, dev):
     """The contract's timed region: `warmup` untimed steps, then exactly `steps` steps bracketed by
-    synchronise + barrier on both sides; returns the MAX elapsed seconds over ranks."""
+    synchronise + barrier on both sides; returns the MAX elapsed seconds over ranks.  Every rank's own time (its K
+    steps done, before the closing barrier) is gathered into PER_RANK_MS: a straggler shows up there, not only in
+    the maximum."""
     for _ in range(warmup):
         step()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)  # sync_all() starts with the same call: no extra wait inside the timed region
+    own = time.perf_counter() - t0
     sync_all()
     elapsed = time.perf_counter() - t0
+    own_all = [own]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([own], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)
+        own_all = [float(v.item()) for v in every]
+    PER_RANK_MS[:] = [round(1e3 * o / steps, 3) for o in own_all]
     return elapsed
 
 
@@ -103,7 +117,8 @@ def protocol_test(args):
         print(json.dumps({"metric": "protocol-test (not a measurement)", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
                           "value": round(world * args.batch * args.seq_len * args.steps / elapsed, 1),
-                          "scaling": "weak", "backend": dist.get_backend() if dist is not None else None,
+                          "scaling": "weak", "per_rank_ms_per_step": list(PER_RANK_MS),
+                          "backend": dist.get_backend() if dist is not None else None,
                           "launched_by": os.environ.get("ESM_AMD_BENCH_LAUNCH", "external-or-single")}), flush=True)
     finish(dist)
 
@@ -182,7 +197,7 @@ def base_result(args, world, metric, value, elapsed, workload, extra_cfg):
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": operand_name(), "data": "synthetic",
         "config": {"workload": workload, "sharding": f"dp{world} (no data-path collective)", **extra_cfg},
-        "host_cores": os.cpu_count(),
+        "host_cores": os.cpu_count(), "per_rank_ms_per_step": list(PER_RANK_MS),
     }
 
 

@@ -23,6 +23,9 @@ def test_two_rank_protocol(tmp_path):
     # rank 1's steps take 10 ms: the MAX over ranks is reported, not rank 0's own 5 ms
     assert 9.5 <= r["ms_per_step"] < 1000, r  # lower bound is the point; the upper one only guards nonsense
     assert abs(r["value"] - 2 * 64 * 1022 * 4 / (r["ms_per_step"] * 4e-3)) / r["value"] < 1e-3
+    # every rank's OWN time is in the line as well: rank 0 ~5 ms per step, rank 1 ~10 ms (the straggler is visible)
+    own = r["per_rank_ms_per_step"]
+    assert len(own) == 2 and 4.5 <= own[0] < own[1] and 9.5 <= own[1] <= r["ms_per_step"] + 1e-3, r
 
 
 def test_self_spawned_two_rank_protocol(tmp_path):
@@ -67,6 +70,7 @@ def test_single_process_protocol():
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert r["n_gpus"] == 1 and 4.5 <= r["ms_per_step"] < 1000
+    assert len(r["per_rank_ms_per_step"]) == 1 and r["per_rank_ms_per_step"][0] <= r["ms_per_step"] + 1e-3
 
 
 def test_argmax_report():
