@@ -12,11 +12,28 @@ stores its outputs under ``tests/golden/``; ``tests/test_oracle.py`` checks this
 fixtures to <= 2e-5.
 
 It works on a state dict (reference key names) — it does not use esm_amd's modules.
+
+``inject`` (default None: nothing is touched, the fp32 reference computation): ``(kinds, dtype)`` rounds the named
+operand groups to a 16-bit dtype and back before they enter a contraction — "W" linear-layer weights, "A" linear-layer
+inputs, "QK" rotated q / k, "V" values, "P" softmax probabilities.  With all five it is the accuracy FLOOR of any engine
+that feeds 16-bit operands to fp32-accumulating matrix cores; tools/esm2_precision_study.py and the parity tests
+read the HIP engine's error against it.
 """
 import math
 
 import torch
 import torch.nn.functional as F
+
+
+ALL_OPERANDS = ("W", "A", "QK", "V", "P")
+
+
+def _rnd(t, inject, kind):
+    return t if inject is None or kind not in inject[0] else t.to(inject[1]).float()
+
+
+def _linear(x, w, b, inject):
+    return F.linear(_rnd(x, inject, "A"), _rnd(w, inject, "W"), b)
 
 
 def gelu(x):
@@ -46,7 +63,7 @@ def apply_rope(x, cos, sin):
     return x * cos + rot * sin
 
 
-def attention_layer(sd, prefix, x, heads, pad_mask, need_weights, use_rope=True):
+def attention_layer(sd, prefix, x, heads, pad_mask, need_weights, use_rope=True, inject=None):
     """Self-attention of one TransformerLayer on x [B,T,E] (reference works on [T,B,E], the math
     is layout independent).  reference esm/multihead_attention.py:256-261 (projections, q scaling),
     :280-284 (head split), :354-355 (rotary), :357 (scores), :368-374 (key padding -inf),
@@ -54,31 +71,32 @@ def attention_layer(sd, prefix, x, heads, pad_mask, need_weights, use_rope=True)
     B, T, E = x.shape
     d = E // heads
     p = prefix + "self_attn."
-    q = F.linear(x, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"]) * (d ** -0.5)
-    k = F.linear(x, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"])
-    v = F.linear(x, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"])
+    q = _linear(x, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"], inject) * (d ** -0.5)
+    k = _linear(x, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"], inject)
+    v = _linear(x, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"], inject)
     q, k, v = (t.view(B, T, heads, d).transpose(1, 2) for t in (q, k, v))  # [B,H,T,d]
     if use_rope:  # ESM-2 (TransformerLayer(use_rotary_embeddings=True), esm2.py:57-66); ESM-1b has none
         cos, sin = rope_tables(T, d, x.device)
         q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
+    q, k = _rnd(q, inject, "QK"), _rnd(k, inject, "QK")
     scores = q @ k.transpose(-1, -2)  # [B,H,T,T]
     if pad_mask is not None:
         scores = scores.masked_fill(pad_mask[:, None, None, :], float("-inf"))
     probs = torch.softmax(scores.float(), dim=-1)
-    ctx = (probs @ v).transpose(1, 2).reshape(B, T, E)
-    out = F.linear(ctx, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
+    ctx = (_rnd(probs, inject, "P") @ _rnd(v, inject, "V")).transpose(1, 2).reshape(B, T, E)
+    out = _linear(ctx, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"], inject)
     return out, (probs if need_weights else None)
 
 
-def transformer_layer(sd, i, x, heads, pad_mask, need_weights, use_rope=True):
+def transformer_layer(sd, i, x, heads, pad_mask, need_weights, use_rope=True, inject=None):
     # reference esm/modules.py:120-142 (pre-LN residual blocks)
     p = f"layers.{i}."
     h = layer_norm(x, sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"])
-    a, probs = attention_layer(sd, p, h, heads, pad_mask, need_weights, use_rope)
+    a, probs = attention_layer(sd, p, h, heads, pad_mask, need_weights, use_rope, inject)
     x = x + a
     h = layer_norm(x, sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"])
-    h = gelu(F.linear(h, sd[p + "fc1.weight"], sd[p + "fc1.bias"]))
-    h = F.linear(h, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+    h = gelu(_linear(h, sd[p + "fc1.weight"], sd[p + "fc1.bias"], inject))
+    h = _linear(h, sd[p + "fc2.weight"], sd[p + "fc2.bias"], inject)
     return x + h, probs
 
 
@@ -104,7 +122,7 @@ def contact_head(sd, tokens, attentions, eos_idx=2, prepend_bos=True, append_eos
 @torch.no_grad()
 def esm2_forward(
     sd, tokens, num_layers, heads, repr_layers=(), need_head_weights=False, return_contacts=False,
-    token_dropout=True, padding_idx=1, mask_idx=32, eos_idx=2, prepend_bos=True, append_eos=True,
+    token_dropout=True, padding_idx=1, mask_idx=32, eos_idx=2, prepend_bos=True, append_eos=True, inject=None,
 ):
     """reference esm/model/esm2.py:77-144.  ``sd``: fp32 state dict with the reference's keys."""
     if return_contacts:
@@ -126,7 +144,7 @@ def esm2_forward(
     pad_mask = pad if bool(pad.any()) else None  # esm2.py:108-109
     attn = []
     for i in range(num_layers):  # esm2.py:111-121
-        x, probs = transformer_layer(sd, i, x, heads, pad_mask, need_head_weights)
+        x, probs = transformer_layer(sd, i, x, heads, pad_mask, need_head_weights, inject=inject)
         if (i + 1) in wanted:
             reps[i + 1] = x
         if need_head_weights:
@@ -135,9 +153,9 @@ def esm2_forward(
     if num_layers in wanted:
         reps[num_layers] = x  # esm2.py:127-128
     # RobertaLMHead, reference esm/modules.py:308-314 (weight tied to the embedding, esm2.py:71-75)
-    h = gelu(F.linear(x, sd["lm_head.dense.weight"], sd["lm_head.dense.bias"]))
+    h = gelu(_linear(x, sd["lm_head.dense.weight"], sd["lm_head.dense.bias"], inject))
     h = layer_norm(h, sd["lm_head.layer_norm.weight"], sd["lm_head.layer_norm.bias"])
-    logits = F.linear(h, sd["embed_tokens.weight"]) + sd["lm_head.bias"]
+    logits = _linear(h, sd["embed_tokens.weight"], None, inject) + sd["lm_head.bias"]
     out = {"logits": logits, "representations": reps}
     if need_head_weights:
         attentions = torch.stack(attn, 1)  # [B,L,H,T,T], esm2.py:132-139

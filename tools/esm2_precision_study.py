@@ -17,36 +17,17 @@ import sys
 import time
 
 import torch
-import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from esm_amd.synth import ESM2_DIMS, synth_esm2_state_dict, synth_tokens  # noqa: E402
-from oracle.esm2_oracle import apply_rope, gelu, layer_norm, rope_tables  # noqa: E402
+from oracle.esm2_oracle import esm2_forward  # noqa: E402
 
 
 def forward(sd, toks, L, H, inj, dt):
-    """reference esm/model/esm2.py:77-128 without padding / token dropout specifics (no <mask>, no <pad> in the study)"""
-    r = lambda t, key: t.to(dt).float() if key in inj else t
-    lin = lambda x, w, b: F.linear(r(x, "A"), r(w, "W"), b)
-    x = sd["embed_tokens.weight"][toks] * (1 - 0.15 * 0.8)  # token-dropout rescale with no <mask> present, esm2.py:86-92
-    B, T, E = x.shape
-    d = E // H
-    cos, sin = rope_tables(T, d)
-    for i in range(L):
-        p = f"layers.{i}."
-        h = layer_norm(x, sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"])
-        q = lin(h, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"]) * d ** -0.5
-        k = lin(h, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"])
-        v = lin(h, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"])
-        q, k, v = (t.view(B, T, H, d).transpose(1, 2) for t in (q, k, v))
-        q, k = r(apply_rope(q, cos, sin), "QK"), r(apply_rope(k, cos, sin), "QK")
-        probs = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
-        ctx = (r(probs, "P") @ r(v, "V")).transpose(1, 2).reshape(B, T, E)
-        x = x + lin(ctx, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
-        h = layer_norm(x, sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"])
-        h = gelu(lin(h, sd[p + "fc1.weight"], sd[p + "fc1.bias"]))
-        x = x + lin(h, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
-    return layer_norm(x, sd["emb_layer_norm_after.weight"], sd["emb_layer_norm_after.bias"])
+    """representations[L] of the oracle (reference esm/model/esm2.py:77-128) with the operand groups `inj` rounded to
+    `dt` (oracle/esm2_oracle.py: `inject`); inj = () is the plain fp32 reference computation"""
+    out = esm2_forward(sd, toks, L, H, repr_layers=[L], inject=(frozenset(inj), dt) if inj else None)
+    return out["representations"][L]
 
 
 def main():
