@@ -325,7 +325,25 @@ def run_esm2_650m(args, dist, rank, world, dev):
             "rel_l2_repr_diff_vs_cpu": ((r_gpu - r_ref).norm() / r_ref.norm()).item(),
             **amax, "sample_sequences": 4,
         }
+        result["parity"]["operand_floor_same_inputs"] = operand_floor_report(sd, s4, L, H, r_ref)
     return result
+
+
+def operand_floor_report(sd, toks_cpu, L, H, r_ref):
+    """The CPU sample once more through the oracle with every MFMA operand (weights, GEMM inputs, q, k, v, P) rounded
+    to the operand dtype: the accuracy floor of ANY 16-bit-operand engine on these inputs, to read the engine's own
+    `parity` numbers against.  Test infrastructure on the CPU leg only; never costs the JSON line."""
+    try:
+        from oracle.esm2_oracle import ALL_OPERANDS, esm2_forward
+
+        odt = torch.bfloat16 if operand_name() == "bf16" else torch.float16
+        fl = esm2_forward(sd, toks_cpu, L, H, repr_layers=[L], inject=(frozenset(ALL_OPERANDS), odt))
+        fl = fl["representations"][L].double()
+        return {"rel_repr_diff_vs_cpu": ((fl - r_ref).abs().max() / r_ref.abs().max()).item(),
+                "rel_l2_repr_diff_vs_cpu": ((fl - r_ref).norm() / r_ref.norm()).item(),
+                "what": f"fp32 oracle with {operand_name()} rounding injected at every operand point, same sequences"}
+    except Exception as e:
+        return {"error": str(e)}
 
 
 def run_esm2_3b_contacts(args, dist, rank, world, dev):

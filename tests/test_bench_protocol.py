@@ -89,3 +89,31 @@ def test_argmax_report():
     assert abs(r["logits_argmax_agreement"] - 2 / 3) < 1e-6
     assert r["decided_positions"] == 2 and r["argmax_agreement_where_decided"] == 1.0
     assert abs(r["logits_max_abs_diff"] - 0.002) < 1e-6
+
+
+def test_operand_floor_report(monkeypatch):
+    """The `parity.operand_floor_same_inputs` block of the bench line: the oracle with operand rounding injected, on
+    the CPU sample; fp16 by default, bf16 when the bench runs bf16 operands; an error never costs the line."""
+    import importlib.util
+    import sys
+
+    import torch
+
+    sys.path.insert(0, ROOT)
+    from esm_amd.synth import synth_esm2_state_dict, synth_tokens
+    from oracle.esm2_oracle import esm2_forward
+
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    L, E, H = 3, 128, 2
+    sd = synth_esm2_state_dict(L, E, H, seed=1)
+    toks = synth_tokens(2, 48, seed=2)
+    ref = esm2_forward(sd, toks, L, H, repr_layers=[L])["representations"][L].double()
+    monkeypatch.delenv("ESM_AMD_OPERAND", raising=False)
+    f16 = bench.operand_floor_report(sd, toks, L, H, ref)
+    assert 2e-5 < f16["rel_l2_repr_diff_vs_cpu"] < 2e-3 and f16["rel_repr_diff_vs_cpu"] > 0 and "f16" in f16["what"]
+    monkeypatch.setenv("ESM_AMD_OPERAND", "bf16")
+    b16 = bench.operand_floor_report(sd, toks, L, H, ref)
+    assert b16["rel_l2_repr_diff_vs_cpu"] > 4 * f16["rel_l2_repr_diff_vs_cpu"] and "bf16" in b16["what"]
+    assert "error" in bench.operand_floor_report(sd, toks, L + 1, H, ref)  # a missing layer: reported, not raised
