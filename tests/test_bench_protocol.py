@@ -117,3 +117,37 @@ def test_operand_floor_report(monkeypatch):
     b16 = bench.operand_floor_report(sd, toks, L, H, ref)
     assert b16["rel_l2_repr_diff_vs_cpu"] > 4 * f16["rel_l2_repr_diff_vs_cpu"] and "bf16" in b16["what"]
     assert "error" in bench.operand_floor_report(sd, toks, L + 1, H, ref)  # a missing layer: reported, not raised
+
+
+def test_secondary_workloads_glue(monkeypatch):
+    """`secondary_workloads` (the other BASELINE configs appended to the default bench line): child runs of this same
+    script, one JSON line parsed per workload, time limits and failures reported instead of raised.  The children
+    run as --protocol-test here (CPU stubs); launcher variables of the parent must not leak into them."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("PYTHONPATH", ROOT)
+    monkeypatch.setenv("RANK", "0")  # as if the parent had been started by a launcher with one rank
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("MASTER_PORT", "1")
+    import time as _t
+
+    out = bench.secondary_workloads(extra=["--protocol-test"], budget_end=_t.perf_counter() + 1000)
+    assert list(out) == ["msa1b", "extract_650m", "esm2_3b_contacts"]
+    for name, r in out.items():
+        assert "error" not in r, (name, r)
+        assert r["metric"].startswith("protocol-test") and r["ms_per_step"] >= 4.5 and r["wall_s"] > 0
+    assert out["esm2_3b_contacts"]["steps"] == 4 and out["extract_650m"]["steps"] == 8 and out["extract_650m"]["warmup"] == 2
+    # a child that fails or overruns its limit is an entry with "error", not an exception
+    monkeypatch.setattr(bench, "SECONDARY", [("bad_flag", ["--no-such-flag"], 60), ("too_slow", ["--steps", "400"], 1)])
+    monkeypatch.setattr(bench, "SECONDARY_MIN_S", 0.5)
+    import time
+
+    out = bench.secondary_workloads(extra=["--protocol-test"], budget_end=time.perf_counter() + 1000)
+    assert "error" in out["bad_flag"] and "exit code" in out["bad_flag"]["error"]
+    assert "error" in out["too_slow"] and "Timeout" in out["too_slow"]["error"]
+    # and once the default run's time budget is spent the remaining children are skipped, not started
+    out = bench.secondary_workloads(extra=["--protocol-test"], budget_end=time.perf_counter() + 0.2)
+    assert all("skipped" in r for r in out.values())
