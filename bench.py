@@ -34,6 +34,7 @@ Prints ONE JSON line (rank 0): metric residues/sec (whole job) plus
                       (--no-secondary skips them), so that one driver run records every BASELINE configuration.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -97,6 +98,24 @@ def timed_steps(step, steps, warmup, sync_all, dist, dev):
         own_all = [float(v.item()) for v in every]
     PER_RANK_MS[:] = [round(1e3 * o / steps, 3) for o in own_all]
     return elapsed
+
+
+@contextlib.contextmanager
+def skip_param_init():
+    """nn.Linear / nn.LayerNorm / nn.Embedding constructors fill their parameters with random numbers (28 s for the 3B
+    model on 8 threads) that the strict load_state_dict right after overwrites: construct without that fill.  Only
+    for models whose every parameter comes from the state dict — which strict loading checks."""
+    import torch.nn as nn
+
+    classes = (nn.Linear, nn.LayerNorm, nn.Embedding)
+    saved = [c.reset_parameters for c in classes]
+    for c in classes:
+        c.reset_parameters = lambda self: None
+    try:
+        yield
+    finally:
+        for c, f in zip(classes, saved):
+            c.reset_parameters = f
 
 
 def finish(dist):
@@ -224,7 +243,8 @@ def run_esm2_650m(args, dist, rank, world, dev):
     FLOP_PER_RESIDUE = 1.4769e9  # SURVEY.md §8 d: 1.509 TFLOP per 1024-token sequence / 1022 residues
     L, E, H = ESM2_DIMS[MODEL]
     sd = synth_esm2_state_dict(L, E, H, seed=0)          # identical replica on every rank
-    model = esm.ESM2(L, E, H).eval()
+    with skip_param_init():
+        model = esm.ESM2(L, E, H).eval()
     model.load_state_dict(sd)
     model = model.to(dev)
     batch = args.batch or 64
@@ -408,7 +428,8 @@ def run_esm2_3b_contacts(args, dist, rank, world, dev):
     T = args.seq_len + 2
     flop_per_seq = L * (24.0 * E * E + 4.0 * T * E) * T  # the transformer stack (SURVEY §8 a); the contact pass
     sd = synth_esm2_state_dict(L, E, H, seed=2)          # recomputes QK^T once more (+2TE per token-layer)
-    model = esm.ESM2(L, E, H).eval()
+    with skip_param_init():
+        model = esm.ESM2(L, E, H).eval()
     model.load_state_dict(sd)
     model = model.to(dev)
     # B = 32: the smallest batch at which every GEMM of the 3B layer (N = 2560 / 5120 / 10240) has a tile count that is
@@ -469,7 +490,8 @@ def run_msa1b(args, dist, rank, world, dev):
                             activation_dropout=0.1, max_positions=1024, embed_positions_msa=True,
                             embed_positions_msa_dim=E, max_tokens=2 ** 14, max_tokens_per_msa=2 ** 14)
     sd = synth_msa_state_dict(L, E, H, F, seed=0)
-    model = esm.MSATransformer(ns, esm.Alphabet.from_architecture("msa_transformer")).eval()
+    with skip_param_init():
+        model = esm.MSATransformer(ns, esm.Alphabet.from_architecture("msa_transformer")).eval()
     model.load_state_dict(sd)
     model = model.to(dev)
     batch = args.batch or 1
@@ -534,7 +556,8 @@ def run_extract_650m(args, dist, rank, world, dev):
     from esm_amd.synth import ESM2_DIMS, synth_esm2_state_dict
 
     L, E, H = ESM2_DIMS["esm2_t33_650M_UR50D"]
-    model = esm.ESM2(L, E, H).eval()
+    with skip_param_init():
+        model = esm.ESM2(L, E, H).eval()
     model.load_state_dict(synth_esm2_state_dict(L, E, H, seed=0))
     model = model.to(dev)
     batch = args.batch or 64

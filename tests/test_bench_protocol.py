@@ -151,3 +151,42 @@ def test_secondary_workloads_glue(monkeypatch):
     # and once the default run's time budget is spent the remaining children are skipped, not started
     out = bench.secondary_workloads(extra=["--protocol-test"], budget_end=time.perf_counter() + 0.2)
     assert all("skipped" in r for r in out.values())
+
+
+def test_skip_param_init_then_strict_load_gives_the_state_dict():
+    """bench.py constructs its models without the constructors' random fill and then loads strictly: every parameter
+    and buffer must come out equal to the synthetic state dict (ESM-2 and MSA Transformer), and the patch must be
+    gone afterwards."""
+    import argparse
+    import importlib.util
+    import sys
+
+    import torch
+
+    sys.path.insert(0, ROOT)
+    import esm
+    from esm_amd.synth import synth_esm2_state_dict, synth_msa_state_dict
+
+    spec = importlib.util.spec_from_file_location("bench_mod4", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    before = torch.nn.Linear.reset_parameters
+    L, E, H = 2, 128, 2
+    sd = synth_esm2_state_dict(L, E, H, seed=3)
+    with bench.skip_param_init():
+        m = esm.ESM2(L, E, H).eval()
+    m.load_state_dict(sd)
+    got = m.state_dict()
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    ns = argparse.Namespace(layers=2, embed_dim=64, ffn_embed_dim=128, attention_heads=2, dropout=0.1,
+                            attention_dropout=0.1, activation_dropout=0.1, max_positions=1024, embed_positions_msa=True,
+                            embed_positions_msa_dim=64, max_tokens=2 ** 14, max_tokens_per_msa=2 ** 14)
+    sdm = synth_msa_state_dict(2, 64, 2, 128, seed=4)
+    with bench.skip_param_init():
+        mm = esm.MSATransformer(ns, esm.Alphabet.from_architecture("msa_transformer")).eval()
+    mm.load_state_dict(sdm)
+    gotm = mm.state_dict()
+    assert set(gotm) == set(sdm) and all(torch.equal(gotm[k], sdm[k]) for k in sdm)
+    assert torch.nn.Linear.reset_parameters is before
+    lin = torch.nn.Linear(8, 8)
+    assert lin.weight.abs().sum() > 0  # constructors fill again outside the context
