@@ -34,7 +34,6 @@ Prints ONE JSON line (rank 0): metric residues/sec (whole job) plus
                       (--no-secondary skips them), so that one driver run records every BASELINE configuration.
 """
 import argparse
-import contextlib
 import json
 import os
 import sys
@@ -98,24 +97,6 @@ def timed_steps(step, steps, warmup, sync_all, dist, dev):
         own_all = [float(v.item()) for v in every]
     PER_RANK_MS[:] = [round(1e3 * o / steps, 3) for o in own_all]
     return elapsed
-
-
-@contextlib.contextmanager
-def skip_param_init():
-    """nn.Linear / nn.LayerNorm / nn.Embedding constructors fill their parameters with random numbers (28 s for the 3B
-    model on 8 threads) that the strict load_state_dict right after overwrites: construct without that fill.  Only
-    for models whose every parameter comes from the state dict — which strict loading checks."""
-    import torch.nn as nn
-
-    classes = (nn.Linear, nn.LayerNorm, nn.Embedding)
-    saved = [c.reset_parameters for c in classes]
-    for c in classes:
-        c.reset_parameters = lambda self: None
-    try:
-        yield
-    finally:
-        for c, f in zip(classes, saved):
-            c.reset_parameters = f
 
 
 def finish(dist):
@@ -237,7 +218,7 @@ def cpu_threads():
 # ---------------------------------------------------------------------------------------------------------------
 def run_esm2_650m(args, dist, rank, world, dev):
     import esm
-    from esm_amd.synth import ESM2_DIMS, synth_esm2_state_dict, synth_tokens
+    from esm_amd.synth import ESM2_DIMS, skip_param_init, synth_esm2_state_dict, synth_tokens
 
     MODEL = "esm2_t33_650M_UR50D"
     FLOP_PER_RESIDUE = 1.4769e9  # SURVEY.md §8 d: 1.509 TFLOP per 1024-token sequence / 1022 residues
@@ -421,7 +402,7 @@ def secondary_workloads(extra=(), budget_end=None):
 
 def run_esm2_3b_contacts(args, dist, rank, world, dev):
     import esm
-    from esm_amd.synth import ESM2_DIMS, synth_esm2_state_dict, synth_tokens
+    from esm_amd.synth import ESM2_DIMS, skip_param_init, synth_esm2_state_dict, synth_tokens
 
     MODEL = "esm2_t36_3B_UR50D"
     L, E, H = ESM2_DIMS[MODEL]
@@ -482,7 +463,7 @@ def run_esm2_3b_contacts(args, dist, rank, world, dev):
 
 def run_msa1b(args, dist, rank, world, dev):
     import esm
-    from esm_amd.synth import MSA_DIMS, synth_msa_state_dict, synth_msa_tokens
+    from esm_amd.synth import MSA_DIMS, skip_param_init, synth_msa_state_dict, synth_msa_tokens
 
     L, E, H, F = MSA_DIMS["esm_msa1b_t12_100M_UR50S"]
     R, C = 128, 513
@@ -553,7 +534,7 @@ def run_extract_650m(args, dist, rank, world, dev):
 
     import esm
     from esm_amd.extract import default_writer_threads, extract, make_embed_fn
-    from esm_amd.synth import ESM2_DIMS, synth_esm2_state_dict
+    from esm_amd.synth import ESM2_DIMS, skip_param_init, synth_esm2_state_dict
 
     L, E, H = ESM2_DIMS["esm2_t33_650M_UR50D"]
     with skip_param_init():

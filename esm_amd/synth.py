@@ -8,6 +8,7 @@ with small random weights attention is ~1/T everywhere and RoPE / masking / head
 numerically muted — while the stack stays non-chaotic end to end.
 """
 import argparse
+import contextlib
 import os
 import zlib
 
@@ -23,6 +24,24 @@ ESM2_DIMS = {
     "esm2_t48_15B_UR50D": (48, 5120, 40),
 }
 
+
+
+@contextlib.contextmanager
+def skip_param_init():
+    """Construct a model WITHOUT the random fill that nn.Linear / nn.LayerNorm / nn.Embedding constructors give their
+    parameters (28 s for the 3B architecture on 8 threads) when a strict ``load_state_dict`` of a complete synthetic
+    state dict follows right away — which is what checks that nothing stays uninitialised.  Bench and tests only."""
+    import torch.nn as nn
+
+    classes = (nn.Linear, nn.LayerNorm, nn.Embedding)
+    saved = [c.reset_parameters for c in classes]
+    for c in classes:
+        c.reset_parameters = lambda self: None
+    try:
+        yield
+    finally:
+        for c, f in zip(classes, saved):
+            c.reset_parameters = f
 
 def esm2_param_shapes(num_layers, embed_dim, heads, vocab=33):
     """State-dict keys and shapes of ESM2 (reference esm/model/esm2.py:40-75)."""

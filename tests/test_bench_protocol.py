@@ -165,15 +165,12 @@ def test_skip_param_init_then_strict_load_gives_the_state_dict():
 
     sys.path.insert(0, ROOT)
     import esm
-    from esm_amd.synth import synth_esm2_state_dict, synth_msa_state_dict
+    from esm_amd.synth import skip_param_init, synth_esm2_state_dict, synth_msa_state_dict
 
-    spec = importlib.util.spec_from_file_location("bench_mod4", os.path.join(ROOT, "bench.py"))
-    bench = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bench)
     before = torch.nn.Linear.reset_parameters
     L, E, H = 2, 128, 2
     sd = synth_esm2_state_dict(L, E, H, seed=3)
-    with bench.skip_param_init():
+    with skip_param_init():
         m = esm.ESM2(L, E, H).eval()
     m.load_state_dict(sd)
     got = m.state_dict()
@@ -182,7 +179,7 @@ def test_skip_param_init_then_strict_load_gives_the_state_dict():
                             attention_dropout=0.1, activation_dropout=0.1, max_positions=1024, embed_positions_msa=True,
                             embed_positions_msa_dim=64, max_tokens=2 ** 14, max_tokens_per_msa=2 ** 14)
     sdm = synth_msa_state_dict(2, 64, 2, 128, seed=4)
-    with bench.skip_param_init():
+    with skip_param_init():
         mm = esm.MSATransformer(ns, esm.Alphabet.from_architecture("msa_transformer")).eval()
     mm.load_state_dict(sdm)
     gotm = mm.state_dict()

@@ -78,14 +78,15 @@ def argmax_check(logits, ref_logits, mask=None):
 @pytest.fixture(scope="module")
 def model_3b():
     import esm
-    from esm_amd.synth import synth_esm2_state_dict
+    from esm_amd.synth import skip_param_init, synth_esm2_state_dict
 
     fix = fixture("esm2_3b_T258")
     d = fix["dims"]
     sd = synth_esm2_state_dict(d["L"], d["E"], d["H"], seed=d["seed"])
     chk = GEN.checksum(sd)
     assert abs(chk - fix["weights_checksum"]) < 1e-6 * abs(chk), "synthetic weight generator drifted"
-    m = esm.ESM2(d["L"], d["E"], d["H"]).eval()
+    with skip_param_init():  # strict load right below
+        m = esm.ESM2(d["L"], d["E"], d["H"]).eval()
     m.load_state_dict(sd)
     del sd
     return m.cuda()

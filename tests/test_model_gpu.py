@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import esm
-from esm_amd.synth import synth_esm2_state_dict, synth_tokens
+from esm_amd.synth import skip_param_init, synth_esm2_state_dict, synth_tokens
 from oracle.esm2_oracle import esm2_forward
 
 pytestmark = pytest.mark.gpu
@@ -46,7 +46,8 @@ def contact_errors(c, cr):
 
 def build(L, E, H, seed, dtype=None):
     sd = synth_esm2_state_dict(L, E, H, seed=seed)
-    m = esm.ESM2(L, E, H).eval()
+    with skip_param_init():  # every parameter comes from sd (strict load): no 28-s random fill of a 3B model first
+        m = esm.ESM2(L, E, H).eval()
     m.load_state_dict(sd)
     m = m.cuda()
     return m, sd
