@@ -282,6 +282,10 @@ __global__ __launch_bounds__(256, 2) void contact_accum64_kernel(
     const int qr = min(q0 + lm, Tlen - 1);
     const int nblk = min(4, (Tlen - kc + 31) >> 5);
     const bool qkeep = q0 + lm < Tlen && residue_mask(tok, q0 + lm, Tlen, pad_idx, eos_idx, bos, eos) != 0.f;
+    // does the wave's 128-key chunk hold a masked key (<cls>, <eos>, a pad, the sequence end)?  wave uniform, the same
+    // for every head: 6 of the 8 chunks of a full-length sequence do not
+    const unsigned masked_blocks = __builtin_amdgcn_readfirstlane(
+        __builtin_amdgcn_ballot_w64(kbr[0] != 0.f || kbr[1] != 0.f || kbr[2] != 0.f || kbr[3] != 0.f) != 0 ? 1u : 0u);
 
     // fp32 VALU instructions take 4 cycles per wave on gfx950 (PMC: 4.5 cycles per VALU instruction in this kernel)
     // and the packed forms process two values in the same 4: the per-score arithmetic is written on float pairs
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void contact_accum64_kernel(
                 // lane idx & 31 == lm for both halves: qkeep is the mask of query q0 + (idx & 31)
                 const int qq = min(q0 + (idx & 31), Tlen - 1);
                 const float v = lse[((size_t)b * H + hs + (idx >> 5)) * Tlen + qq];  // log2 domain
-                s_lse[idx] = qkeep ? v : __builtin_inff();
+                s_lse[idx] = qkeep ? -v : -__builtin_inff();  // stored NEGATED: it is the start value of the score accumulators
             }
         }
         for (int hd = hs; hd < he; ++hd) {
@@ -316,40 +320,50 @@ __global__ __launch_bounds__(256, 2) void contact_accum64_kernel(
             if (active) {
                 const char* sk = s_k + cur * KBUF;
                 load_q(qn, min(hd + 1, h1 - 1));
-                f32x2 cr[8], rs[8];
+                // -lse of the 16 query rows this lane holds (a masked query: -inf, its row comes out as exact zeros).  The
+                // score accumulators of every block START from it — one set of 16 registers per head, kept intact by
+                // the early-clobber MFMA of common.h — so a score leaves the matrix pipe as s - lse: no 16 v_mov per
+                // block to seed the accumulator, no packed add per score pair.  The key bias (0 / -inf) is added
+                // afterwards, and only by waves whose chunk holds a masked key.
+                f32x16 nlse;
+                f32x2 rs[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    cr[i] = f32x2{-s_lse[(hd - hs) * 32 + mfma32_row(2 * i, hh)],
-                                  -s_lse[(hd - hs) * 32 + mfma32_row(2 * i + 1, hh)]};
-                    rs[i] = f32x2{0.f, 0.f};
-                }
+                for (int r = 0; r < 16; ++r) nlse[r] = s_lse[(hd - hs) * 32 + mfma32_row(r, hh)];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rs[i] = f32x2{0.f, 0.f};
                 const float wl = wreg[layer * H + hd];
                 const f32x2 wl2 = f32x2{wl, wl};
+                // two copies of the block loop, chosen per wave: hipcc turns a per-block "add the key bias if the block
+                // has a masked key" into 16 v_cndmask per block, which costs more than it saves
+                auto blocks = [&](auto any_masked_c) {
+                    constexpr bool ANY_MASKED = decltype(any_masked_c)::value;
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    if (jj < nblk) {  // wave uniform
-                        f32x16 s;
+                    for (int jj = 0; jj < 4; ++jj) {
+                        if (jj < nblk) {  // wave uniform
+                            f32x16 s = Op<T>::mma_keep_c(qf[0], *reinterpret_cast<const V8*>(sk + jj * 4096 + xo[0]), nlse);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) s[r] = kbr[jj];
+                            for (int ks = 1; ks < 4; ++ks) {
+                                const V8 kf = *reinterpret_cast<const V8*>(sk + jj * 4096 + xo[ks]);
+                                s = Op<T>::mma(qf[ks], kf, s);
+                            }
+                            f32x2 cs2 = f32x2{0.f, 0.f};
 #pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) {
-                            const V8 kf = *reinterpret_cast<const V8*>(sk + jj * 4096 + xo[ks]);
-                            s = Op<T>::mma(qf[ks], kf, s);
+                            for (int i = 0; i < 8; ++i) {
+                                // 2^(s + key_bias - lse) with log2-domain scores; -inf stays -inf -> 0
+                                f32x2 t = f32x2{s[2 * i], s[2 * i + 1]};
+                                if constexpr (ANY_MASKED) t += f32x2{kbr[jj], kbr[jj]};
+                                const f32x2 p = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                                acc[jj][i] = __builtin_elementwise_fma(wl2, p, acc[jj][i]);
+                                rs[i] += p;
+                                cs2 += p;
+                            }
+                            const float cs = half_swap_sum(cs2[0] + cs2[1]);  // the lane halves hold different query rows
+                            if (hh == 0) s_col[(hd - hs) * 128 + jj * 32 + lm] = cs;
                         }
-                        f32x2 cs2 = f32x2{0.f, 0.f};
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            // 2^(s + key_bias - lse) with log2-domain scores; -inf stays -inf -> 0
-                            const f32x2 t = f32x2{s[2 * i], s[2 * i + 1]} + cr[i];
-                            const f32x2 p = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                            acc[jj][i] = __builtin_elementwise_fma(wl2, p, acc[jj][i]);
-                            rs[i] += p;
-                            cs2 += p;
-                        }
-                        const float cs = half_swap_sum(cs2[0] + cs2[1]);  // the lane halves hold different query rows
-                        if (hh == 0) s_col[(hd - hs) * 128 + jj * 32 + lm] = cs;
                     }
-                }
+                };
+                if (masked_blocks == 0) blocks(std::false_type{});
+                else blocks(std::true_type{});
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = row16_sum(rs[r >> 1][r & 1]);

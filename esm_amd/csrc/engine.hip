@@ -249,6 +249,9 @@ void esmk_destroy(esmk_model* m) {
     if (m->d_usin) (void)hipFree(m->d_usin);
     if (m->pk_host) (void)hipHostFree(m->pk_host);
     if (m->pk_event) (void)hipEventDestroy(m->pk_event);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
     delete m;
 }
 
@@ -635,6 +638,17 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
     }
     if (repr_copy(0, x)) return 1;  // esm2.py:99-100
 
+    // ESMK_QKV_FORK=1: q/k and v projections side by side on two streams (see esmk_model::side_stream)
+    static const bool env_fork = [] {
+        const char* e = getenv("ESMK_QKV_FORK");
+        return e != nullptr && atoi(e) != 0;
+    }();
+    const bool fork_v = env_fork && !m->prof_on;
+    if (fork_v && !m->side_stream) {
+        ESMK_TRY(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+        ESMK_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+        ESMK_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    }
     GemmArgs g;
     for (int l = 0; l < L; ++l) {  // esm2.py:111-121 -> modules.py:120-142
         const LayerOff& o = m->layer[l];
@@ -665,12 +679,24 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         g.scaling = kLog2e / sqrtf((float)m->D);
         g.head_dim = m->D == 128 ? 128 : 64;
         g.row_pos = row_pos;
-        if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;  // q, k: weight rows [0,2EA)
-        g.row_pos = nullptr;
-        g.W = pk + o.wqkv + (size_t)2 * EA * Kp * os;           // v: weight rows [2EA,3EA)
-        g.bias = (const float*)(pk + o.bqkv) + 2 * EA;
-        g.N = EA;
-        if (gemm(PC_GEMM_QKV, g, EPI_V_T, os)) return 1;
+        GemmArgs gv = g;
+        gv.row_pos = nullptr;
+        gv.W = pk + o.wqkv + (size_t)2 * EA * Kp * os;           // v: weight rows [2EA,3EA)
+        gv.bias = (const float*)(pk + o.bqkv) + 2 * EA;
+        gv.N = EA;
+        if (fork_v) {
+            // v on the side stream, after everything queued so far (the LayerNorm that wrote h, the V^T clear); the
+            // attention below waits for it.  Not under the per-class profiler: its events live on one stream.
+            ESMK_TRY(hipEventRecord(m->ev_fork, st));
+            ESMK_TRY(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
+            ESMK_TRY(launch_gemm(gv, EPI_V_T, op, m->side_stream));
+            ESMK_TRY(hipEventRecord(m->ev_join, m->side_stream));
+            if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;  // q, k: weight rows [0,2EA)
+            ESMK_TRY(hipStreamWaitEvent(st, m->ev_join, 0));
+        } else {
+            if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;  // q, k: weight rows [0,2EA)
+            if (gemm(PC_GEMM_QKV, gv, EPI_V_T, os)) return 1;
+        }
         {
             // 4 T d flop per (query, head) pair: QK^T and PV; q,k,v read + ctx written
             ProfScope ps(m, st, PC_ATTENTION, pc ? 4.0 * pc->sum_len2 * E : 4.0 * N * (double)T * E, 4 * NE * os);

@@ -78,6 +78,11 @@ struct esmk_model {
     int32_t* pk_host = nullptr;
     size_t pk_host_cap = 0;
     hipEvent_t pk_event = nullptr;
+    // ESMK_QKV_FORK: the v projection of a layer runs on a stream of the library's own, next to the q/k projection on
+    // the caller's stream (both only read the normalised rows): when neither launch fills a whole number of rounds
+    // over the CUs (small batches, MSA row counts), the workgroups of one take the CUs the other leaves idle
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // MSA Transformer (esmk_msa_create)
     bool is_msa = false;
     int npos = 0, has_msa_pos = 0;

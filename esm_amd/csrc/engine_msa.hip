@@ -239,6 +239,17 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
         return 0;
     };
 
+    static const bool env_fork = [] {
+        const char* e = getenv("ESMK_QKV_FORK");
+        return e != nullptr && atoi(e) != 0;
+    }();
+    const bool fork_v = env_fork && !m->prof_on;
+    if (fork_v && !m->side_stream) {
+        ESMK_TRY(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+        ESMK_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+        ESMK_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    }
+
     // msa_transformer.py:152-172: token + position + MSA-row embeddings, LayerNorm, pads zeroed
     {
         ProfScope ps(m, st, PC_EMBED, 0, (double)N * 8 + 4 * NE);
@@ -273,13 +284,23 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
         g.Tp = Tp;
         g.scaling = scaling;
         g.row_keep = row_keep;
+        GemmArgs gv = g;
+        gv.row_keep = nullptr;
+        gv.W = pk + a.wqkv + (size_t)2 * E * E * os;
+        gv.bias = (const float*)(pk + a.bqkv) + 2 * E;
+        gv.N = E;
+        gv.vt_rows = vt_rows;
+        if (fork_v) {  // v next to q/k on the library's side stream (esmk_model::side_stream, ESMK_QKV_FORK)
+            ESMK_TRY(hipEventRecord(m->ev_fork, st));
+            ESMK_TRY(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
+            ESMK_TRY(launch_gemm(gv, EPI_V_T, op, m->side_stream));
+            ESMK_TRY(hipEventRecord(m->ev_join, m->side_stream));
+            if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;
+            ESMK_TRY(hipStreamWaitEvent(st, m->ev_join, 0));
+            return 0;
+        }
         if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;
-        g.row_keep = nullptr;
-        g.W = pk + a.wqkv + (size_t)2 * E * E * os;
-        g.bias = (const float*)(pk + a.bqkv) + 2 * E;
-        g.N = E;
-        g.vt_rows = vt_rows;
-        return gemm(PC_GEMM_QKV, g, EPI_V_T, os);
+        return gemm(PC_GEMM_QKV, gv, EPI_V_T, os);
     };
     auto out_proj = [&](const AttnOff& a, int map_R, int map_C) -> int {
         GemmArgs g;

@@ -183,10 +183,8 @@ ESMK_DEV void epilogue_wave(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, 
                 for (int i = 0; i < 4; ++i) {
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[j][i][4 * g + e] + bv[e];
-                        if constexpr (EPI == EPI_GELU_T) v[e] = gelu_fast(v[e]);
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e] + bv[e];
+                    if constexpr (EPI == EPI_GELU_T) gelu_fast_x4(v);
                     *reinterpret_cast<V4*>(wl + lds_a(32 * i + lm, 4 * j + g) + 8 * h) =
                         pack4<T>(v[0], v[1], v[2], v[3]);
                 }
@@ -221,10 +219,8 @@ ESMK_DEV void epilogue_wave(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, 
                         const int i = 2 * hp + ii;
                         f32x4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = acc[j][i][4 * g + e] + bv[e];
-                            if constexpr (EPI == EPI_GELU_F32) v[e] = gelu_fast(v[e]);
-                        }
+                        for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e] + bv[e];
+                        if constexpr (EPI == EPI_GELU_F32) gelu_fast_x4(v);
                         *reinterpret_cast<f32x4*>(wl + lds_b(32 * ii + lm, 8 * j + 2 * g + h)) = v;
                     }
                 }

@@ -247,10 +247,8 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
                 for (int g = 0; g < 4; ++g) {
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[j][i][4 * g + e];
-                        if constexpr (EPI == EPI_GELU_T) v[e] = gelu_fast(v[e]);
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
+                    if constexpr (EPI == EPI_GELU_T) gelu_fast_x4(v);
                     *reinterpret_cast<V4*>(wl + lm * 128 + (((4 * j + g) ^ (lm & 7)) << 4) + 8 * h) =
                         pack4_<T>(v[0], v[1], v[2], v[3]);
                 }
@@ -304,10 +302,8 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
             for (int g = 0; g < 4; ++g) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[j][i][4 * g + e];
-                    if constexpr (EPI == EPI_GELU_F32) v[e] = gelu_fast(v[e]);
-                }
+                for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
+                if constexpr (EPI == EPI_GELU_F32) gelu_fast_x4(v);
                 *reinterpret_cast<f32x4*>(wl + lm * 128 + (((2 * g + h) ^ (lm & 7)) << 4)) = v;
             }
             f32x4 vv[4];

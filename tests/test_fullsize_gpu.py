@@ -117,7 +117,7 @@ def _check_3b(model, name):
     print(f"\n{name}: {report}; logits abs err {lerr:.2e}, argmax raw {raw:.4f}, decided ok {decided_ok}")
     for b, r in report.items():
         assert r["repr_rel_l2"] < 1e-3, (b, r)          # the contract in the L2 sense
-        assert r["repr_rel_max"] < 1.5e-3, (b, r)       # worst single element of 36 fp16-operand layers
+        assert r["repr_rel_max"] < 1e-3, (b, r)         # the contract in the max norm as well (round-3 ruling: full-size fixtures keep hard bounds)
         assert r["contact_logit_rel"] < 3e-3 and r["contact_prob"] < 1e-2, (b, r)
         assert r["fused_vs_materialised"] < 1e-4, (b, r)
     assert decided_ok and raw > 0.98

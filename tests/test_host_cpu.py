@@ -250,7 +250,7 @@ def test_extract_embed_fn_dispatch():
 
 
 def test_gelu_polynomial_of_the_epilogues_matches_erf():
-    """experiments/gelu_poly (measured in round 2, not yet in the library): GELU as x (0.5 + u Q(t)); replay that
+    """The GELU of the GEMM epilogues (esm_amd/csrc/common.h: gelu_fast) is x (0.5 + u Q(t)); replay that
     evaluation in emulated fp32 (one rounding per FMA) and hold it against float64 erf (reference esm/modules.py:17-24).
     Bound: 2e-6 absolute inside the clamp, 2e-6 |x| beyond — two orders below the fp16 rounding of the stored value."""
     import sys
@@ -261,7 +261,7 @@ def test_gelu_polynomial_of_the_epilogues_matches_erf():
     sys.path.insert(0, os.path.join(root, "tools"))
     import fit_gelu_poly as fg
 
-    src = open(os.path.join(root, "experiments", "gelu_poly", "gelu_poly.h")).read()
+    src = open(os.path.join(root, "esm_amd", "csrc", "common.h")).read()
     body = re.search(r"#define ESMK_GELU_COEF\s*\\\s*\{(.*?)\}", src, re.S).group(1).replace("\\", " ")
     coef = np.array([float(v.rstrip("f")) for v in body.replace("\n", " ").split(",")], dtype=np.float32)
     clamp = float(re.search(r"kGeluClamp = ([0-9.]+)f", src).group(1))

@@ -14,7 +14,7 @@ import torch
 
 import esm
 from esm_amd.synth import skip_param_init, synth_esm2_state_dict, synth_tokens
-from oracle.esm2_oracle import esm2_forward
+from oracle.esm2_oracle import ALL_OPERANDS, esm2_forward
 
 pytestmark = pytest.mark.gpu
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "esm2_*.pt")))  # incl. head_dim 16 (8M)
@@ -36,12 +36,31 @@ def rel_err(a, b, mask=None):
     return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
 
 
-def contact_errors(c, cr):
-    """(max prob error, max logit error where the reference logit is not saturated)."""
+def contact_errors(c, cr, with_range=False):
+    """(max prob error, max logit error where the reference logit is not saturated[, range of those logits])."""
     lg = lambda t: torch.logit(t.double().clamp(1e-12, 1 - 1e-12))
     z, zr = lg(c), lg(cr)
     ok = zr.abs() < 8
-    return (c - cr).abs().max().item(), (z - zr)[ok].abs().max().item() if ok.any() else 0.0
+    perr, zerr = (c - cr).abs().max().item(), (z - zr)[ok].abs().max().item() if ok.any() else 0.0
+    if not with_range:
+        return perr, zerr
+    return perr, zerr, (zr[ok].max() - zr[ok].min()).item() if ok.any() else 1.0
+
+
+def floor_referenced(got, ref, floor, mask=None, contract=REL, slack=1.25):
+    """The parity criterion for deep stacks: the L2 error meets the contract; the max norm — the maximum
+    of that noise over the tensor, which scatters by +-10 % with the seed and re-rolls with any rounding change —
+    stays within `slack` of the max-norm error of the emulated fp16-operand floor on the SAME inputs
+    (oracle `inject`), and within the contract itself wherever the floor is.  Returns (l2, max, bound)."""
+    if mask is not None:
+        got, ref, floor = got[mask], ref[mask], floor[mask]
+    got, ref, floor = got.double(), ref.double(), floor.double()
+    l2 = ((got - ref).norm() / ref.norm()).item()
+    mx = ((got - ref).abs().max() / ref.abs().max()).item()
+    bound = max(contract, slack * ((floor - ref).abs().max() / ref.abs().max()).item())
+    assert l2 < contract, ("L2", l2)
+    assert mx < bound, ("max norm", mx, bound)
+    return l2, mx, bound
 
 
 def build(L, E, H, seed, dtype=None):
@@ -84,10 +103,11 @@ def test_engine_matches_reference_fixture(path):
     # contact probabilities: logit-level error (reference tolerance convention atol=1e-3)
     c, cr = out["contacts"].cpu(), fix["contacts"]
     assert c.shape == cr.shape
-    perr, zerr = contact_errors(c, cr)
+    perr, zerr, zrange = contact_errors(c, cr, with_range=True)
     # the random regression (std 4 over L*H channels) amplifies the ~5e-3 score error of fp16 q,k; the 8M fixture
-    # sums 120 channels (6 layers x 20 heads) and measures 5.2e-3
-    assert perr < (8e-3 if d["L"] * d["H"] > 100 else 5e-3) and zerr < 3e-2, (perr, zerr)
+    # sums 120 channels (6 layers x 20 heads) and measures 5.2e-3.  Logits: the convention of the full-size tests,
+    # error as a fraction of the range of the unsaturated reference logits (5.2 ... 15.8 on these fixtures)
+    assert perr < (8e-3 if d["L"] * d["H"] > 100 else 5e-3) and zerr < 3e-3 * zrange, (perr, zerr, zrange)
 
 
 def test_shape_pin_and_interior_pad():
@@ -135,6 +155,7 @@ def test_3b_dims_contacts_against_oracle():
     with torch.no_grad():
         out = model(toks.cuda(), repr_layers=[36], return_contacts=True)
     ref = esm2_forward(sd, toks, L, H, repr_layers=[36], return_contacts=True)
+    floor = esm2_forward(sd, toks, L, H, repr_layers=[36], inject=(frozenset(ALL_OPERANDS), torch.float16))
     nonpad = toks.ne(1)
     e = rel_err(out["representations"][36].cpu(), ref["representations"][36], nonpad)
     c, cr = out["contacts"].cpu(), ref["contacts"]
@@ -142,7 +163,9 @@ def test_3b_dims_contacts_against_oracle():
     p0, z0 = contact_errors(c[0], cr[0])
     p1, z1 = contact_errors(c[1, :59, :59], cr[1, :59, :59])
     print(f"\n3B-dims: repr rel {e:.2e}; contact prob err {p0:.2e}/{p1:.2e}, logit err {z0:.2e}/{z1:.2e}")
-    assert e < REL_DEEP
+    l2, mx, bound = floor_referenced(out["representations"][36].cpu(), ref["representations"][36],
+                                     floor["representations"][36], nonpad)
+    print(f"3B-dims: repr L2 {l2:.2e}, max norm {mx:.2e} (bound {bound:.2e} = max(1e-3, 1.25 x floor))")
     assert max(p0, p1) < 2e-2 and max(z0, z1) < 1e-1, (p0, p1, z0, z1)
     # the same map without the [2,36,40,96,96] attention tensor (csrc/contacts.hip; 1440 channels, 40 heads)
     with torch.no_grad():

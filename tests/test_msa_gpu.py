@@ -72,7 +72,19 @@ def test_msa_engine_matches_oracle_at_100M_dims(B, R, C, pads):
     # tied row attention sums R*64 fp16 products per score: the probability error grows with the MSA depth
     # (measured 3.5e-3 at R = 128 on sharp synthetic attention maps)
     assert (out["row_attentions"].cpu() - ref["row_attentions"]).abs().max().item() < (2e-3 if R <= 32 else 6e-3)
-    assert (out["col_attentions"].cpu() - ref["col_attentions"]).abs().max().item() < 2e-3
+    # column maps: against the emulated fp16-operand floor of the same inputs (the (2, 7, 65) case has a floor of
+    # 1.9e-3 — a fixed 2e-3 sat 5 % above it and flipped with any change of the rounding pattern)
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import msa_precision_study as study
+
+    h16 = torch.float16
+    floor = study.run(sd, toks, L, H, study.Inject(weights=h16, acts=h16, qkv=h16, probs=h16))
+    col_floor = (floor["col_attentions"] - ref["col_attentions"]).abs().max().item()
+    col_err = (out["col_attentions"].cpu() - ref["col_attentions"]).abs().max().item()
+    print(f"MSA ({B},{R},{C}): column maps {col_err:.2e}, floor {col_floor:.2e}")
+    assert col_err < max(2e-3, 1.25 * col_floor), (col_err, col_floor)
     # R = 128 with the sharp (qk_gain 2) synthetic weights is the ill-conditioned regime of DESIGN.md §2 already
     # at two layers: 5.3e-3 measured
     assert (out["contacts"].cpu() - ref["contacts"]).abs().max().item() < (5e-3 if R <= 32 else 8e-3)
