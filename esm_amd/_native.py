@@ -100,6 +100,7 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     ),
     "esmk_debug_gemm_timing": (c_int, [c_void_p]),
+    "esmk_debug_gemm_impl": (c_int, [c_int, c_int]),
     "esmk_debug_linear_splitk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "esmk_op_qkv_rope": (
         c_int,

@@ -926,6 +926,13 @@ int esmk_debug_linear_splitk(const void* a_dev, const void* w_dev, float* partia
 
 int esmk_debug_gemm_timing(void* stamps_dev) {
     gemm8_set_timing((unsigned long long*)stamps_dev);
+    gemm9_set_timing((unsigned long long*)stamps_dev);
+    return 0;
+}
+
+int esmk_debug_gemm_impl(int impl, int variant) {
+    if (impl != 8 && impl != 9) return fail("esmk_debug_gemm_impl: impl must be 8 or 9");
+    gemm_set_impl(impl, variant);
     return 0;
 }
 

@@ -561,8 +561,21 @@ static hipError_t dispatch(const GemmArgs& p, int epi, hipStream_t st) {
     return hipErrorInvalidValue;
 }
 
+static int g_impl = -1, g_impl_var = 0;  // -1: not decided yet (ESMK_GEMM_IMPL is read at the first launch)
+void gemm_set_impl(int impl, int var) {
+    g_impl = impl;
+    g_impl_var = var;
+}
+
 hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipErrorInvalidValue;
+    if (g_impl < 0) {
+        const char* e = getenv("ESMK_GEMM_IMPL");  // "9" or "9:<var>"
+        g_impl = (e != nullptr && e[0] == '9') ? 9 : 8;
+        g_impl_var = (e != nullptr && e[0] == '9' && e[1] == ':') ? atoi(e + 2) : 0;
+    }
+    if (g_impl == 9 && !p.force_old && !p.force_generic && !p.dbg && gemm9_supports(p, epi))
+        return launch_gemm9(p, epi, operand_dtype, g_impl_var, st);
     static const bool env_old = [] {
         const char* e = getenv("ESMK_GEMM");
         return e != nullptr && strcmp(e, "old") == 0;

@@ -61,6 +61,13 @@ bool gemm8_half_height(const GemmArgs& p);            // dense kernels: 128 x 25
 hipError_t launch_gemm8(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st);
 // measurement hook: per-tile s_memtime stamps of workgroup-leader lanes ([workgroup][tile & 31][4])
 void gemm8_set_timing(unsigned long long* dev_buf);
+// gemm9.hip: the same contract on one wave per SIMD (128 x 128 wave blocks); dense operands only.  var selects the
+// DMA schedule (0: 8 + 8 pieces, 1: 6 + 5 + 5) or a timing experiment (gemm9.hip)
+bool gemm9_supports(const GemmArgs& p, int epi);
+hipError_t launch_gemm9(const GemmArgs& p, int epi, int operand_dtype, int var, hipStream_t st);
+void gemm9_set_timing(unsigned long long* dev_buf);
+// which persistent kernel launch_gemm picks for dense calls: 8 (default) or 9; ESMK_GEMM_IMPL / esmk_debug_gemm_impl
+void gemm_set_impl(int impl, int var);
 
 // ---- elementwise.hip -------------------------------------------------------------------
 // per-sequence statistics of the token matrix (esm2.py:82,86-92): scale[b] for token dropout,

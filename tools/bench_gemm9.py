@@ -1,0 +1,161 @@
+"""gemm9 (one wave per SIMD, 128 x 128 wave blocks) against gemm8 (two waves per SIMD) and the vendor library on the
+SAME operands, inside one process, interleaved rounds (boxes differ by +-3 %, so variants are only compared in-call).
+
+    python tools/bench_gemm9.py [--B 64] [--rounds 5] [--iters 10] [--check-only] [--no-vendor]
+
+1. correctness: gemm9 must be BIT-IDENTICAL to gemm8 (same MFMA sequence per output element) on ragged shapes, all
+   linear epilogues, fp16 and bf16;
+2. timing: per layer shape and epilogue, median over rounds of HIP-event timed loops, + in-kernel cycle stamps
+   (cycles per K tile, epilogue, seam, effective shader clock).
+"""
+import argparse
+import ctypes
+import math
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from esm_amd import _native as nat  # noqa: E402
+from esm_amd import ops  # noqa: E402
+
+
+def set_impl(impl, var=0):
+    nat.check(nat.lib.esmk_debug_gemm_impl(impl, var))
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def stamps(fn, ntiles, nk):
+    buf = torch.zeros(256 * 32 * 4, dtype=torch.int64, device="cuda")
+    nat.check(nat.lib.esmk_debug_gemm_timing(ctypes.c_void_p(buf.data_ptr())))
+    fn()
+    torch.cuda.synchronize()
+    nat.check(nat.lib.esmk_debug_gemm_timing(ctypes.c_void_p(0)))
+    full = buf.view(256, 32, 4)[:, :max(1, ntiles), :].double().cpu()
+    full = full[full[:, 0, 0] > 0]
+    t = full[:, :, :3]
+    wall = full[:, -1, 3] - full[:, 0, 3]  # 100 MHz ticks
+    cyc = t[:, -1, 2] - t[:, 0, 2]
+    ghz = (cyc / wall.clamp(min=1)).mean().item() * 0.1 if ntiles > 1 else float("nan")
+    loop = (t[:, :, 1] - t[:, :, 0]).mean().item() / nk
+    epi = (t[:, :, 2] - t[:, :, 1]).mean().item()
+    seam = (t[:, 1:, 0] - t[:, :-1, 2]).mean().item() if ntiles > 1 else float("nan")
+    return loop, epi, seam, ghz
+
+
+def check(dt):
+    g = torch.Generator(device="cuda").manual_seed(1)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    bad = 0
+    shapes = [(256, 256, 64), (512, 768, 128), (1000, 1288, 192), (4096, 1280, 1280), (777, 264, 320), (2560, 5120, 1280),
+              (70000, 1280, 1280), (300, 8, 64)]
+    for M, N, K in shapes:
+        a = rnd(M, K).to(dt)
+        w = (rnd(N, K) / math.sqrt(K)).to(dt)
+        bias = rnd(N)
+        for epi in (nat.EPI_STORE_T, nat.EPI_STORE_F32, nat.EPI_GELU_T, nat.EPI_GELU_F32, nat.EPI_RESID_F32):
+            for use_bias in (True, False):
+                outs = []
+                for impl, var in ((8, 0), (9, 0), (9, 1), (9, 4 if (K // 64) % 2 == 0 else 0)):
+                    set_impl(impl, var)
+                    x0 = rnd(M, N) if epi == nat.EPI_RESID_F32 else None
+                    if x0 is not None:
+                        torch.manual_seed(0)
+                        x0 = torch.arange(M * N, device="cuda", dtype=torch.float32).reshape(M, N).sin()
+                    outs.append(ops.linear(a, w, bias if use_bias else None, epi, out=x0).clone())
+                set_impl(8)
+                ref = torch.nn.functional.linear(a.float(), w.float(), bias if use_bias else None)
+                for name, o in (("gemm9/A", outs[1]), ("gemm9/B", outs[2]), ("gemm9/R", outs[3])):
+                    same = torch.equal(o, outs[0])
+                    fin = torch.isfinite(o.float()).all().item()
+                    if not (same and fin):
+                        bad += 1
+                        d = (o.float() - outs[0].float()).abs().max().item()
+                        print(f"MISMATCH {name} dtype={dt} M={M} N={N} K={K} epi={epi} bias={use_bias}: max|d|={d:.3e} finite={fin}",
+                              flush=True)
+                if epi == nat.EPI_STORE_F32:  # and gemm8 itself against fp32 torch (sanity of the reference arm)
+                    e = (outs[0] - ref).abs().max().item() / ref.abs().max().item()
+                    assert e < 5e-3, e
+    print(f"check {dt}: {'OK (bit-identical to gemm8 on all shapes / epilogues)' if bad == 0 else str(bad) + ' MISMATCHES'}", flush=True)
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=64)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--check-only", action="store_true")
+    ap.add_argument("--no-vendor", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--dbg", action="store_true", help="also the timing-experiment variants of gemm9 (plain store only)")
+    args = ap.parse_args()
+    print("device:", torch.cuda.get_device_name(0), flush=True)
+    bad = 0
+    # fp16 subnormal operands through the MFMA (the split-weight precision mode stores W - fp16(W), mostly subnormal)
+    a1 = torch.ones(256, 64, device="cuda", dtype=torch.float16)
+    w1 = torch.full((256, 64), 2.0 ** -20, device="cuda", dtype=torch.float16)
+    o1 = ops.linear(a1, w1, None, nat.EPI_STORE_F32)
+    print(f"fp16 subnormal operand through the MFMA: 64 * 2^-20 -> {o1[0, 0].item():.6e} (exact 6.103516e-05; 0 = flushed)", flush=True)
+    if not args.no_check:
+        bad = check(torch.float16) + check(torch.bfloat16)
+    if args.check_only:
+        sys.exit(1 if bad else 0)
+    T, E, F = 1024, 1280, 5120
+    M = args.B * T
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    dt = torch.float16
+    cases = [("qk store", 2 * E, E, nat.EPI_STORE_T), ("v/out store", E, E, nat.EPI_STORE_T), ("out resid", E, E, nat.EPI_RESID_F32),
+             ("fc1 store", F, E, nat.EPI_STORE_T), ("fc1 gelu", F, E, nat.EPI_GELU_T), ("fc2 store", E, F, nat.EPI_STORE_T),
+             ("fc2 resid", E, F, nat.EPI_RESID_F32)]
+    for name, N, K, epi in cases:
+        a = rnd(M, K).to(dt)
+        w = (rnd(N, K) / math.sqrt(K)).to(dt)
+        bias = rnd(N)
+        out = torch.zeros(M, N, device="cuda") if epi == nat.EPI_RESID_F32 else None
+        flops = 2.0 * M * N * K
+        arms = [("gemm8", 8, 0), ("gemm9/A", 9, 0), ("gemm9/B", 9, 1), ("gemm9/R", 9, 4)]
+        if args.dbg and epi == nat.EPI_STORE_T:
+            arms += [("g9R no-loads", 9, 36), ("g9 no-mfma", 9, 16), ("g9 no-dma", 9, 32), ("g9 no-reads", 9, 64), ("g9 no-epi", 9, 128),
+                     ("g9 mfma-only", 9, 96), ("g9 skeleton", 9, 224)]
+        times = {n: [] for n, _, _ in arms}
+        if not args.no_vendor and epi == nat.EPI_STORE_T:
+            times["vendor"] = []
+            bias_t = bias.to(dt)
+        for _ in range(args.rounds):
+            for n, impl, var in arms:
+                set_impl(impl, var)
+                times[n].append(timeit(lambda: ops.linear(a, w, bias, epi, out=out), args.iters))
+            if "vendor" in times:
+                times["vendor"].append(timeit(lambda: torch.nn.functional.linear(a, w, bias_t), args.iters))
+        nt = ((M + 255) // 256) * ((N + 255) // 256)
+        for n, impl, var in arms:
+            set_impl(impl, var)
+            loop, ep, seam, ghz = stamps(lambda: ops.linear(a, w, bias, epi, out=out), min(32, nt // 256), K // 64)
+            ms = statistics.median(times[n])
+            print(f"{name:12s} {n:12s} {ms*1e3:8.1f} us (min {min(times[n])*1e3:8.1f}) {flops/ms/1e9:7.1f} TFLOP/s | cycles/K-tile {loop:7.1f} "
+                  f"epilogue {ep:7.0f} seam {seam:6.0f} clock {ghz:4.2f} GHz", flush=True)
+        if "vendor" in times:
+            ms = statistics.median(times["vendor"])
+            print(f"{name:12s} {'vendor':12s} {ms*1e3:8.1f} us (min {min(times['vendor'])*1e3:8.1f}) {flops/ms/1e9:7.1f} TFLOP/s", flush=True)
+        set_impl(8)
+        del a, w, out
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
