@@ -931,7 +931,7 @@ int esmk_debug_gemm_timing(void* stamps_dev) {
 }
 
 int esmk_debug_gemm_impl(int impl, int variant) {
-    if (impl != 8 && impl != 9) return fail("esmk_debug_gemm_impl: impl must be 8 or 9");
+    if (impl != 8 && impl != 9 && impl != 0) return fail("esmk_debug_gemm_impl: impl must be 8, 9 or 0 (automatic choice)");
     gemm_set_impl(impl, variant);
     return 0;
 }

@@ -561,7 +561,12 @@ static hipError_t dispatch(const GemmArgs& p, int epi, hipStream_t st) {
     return hipErrorInvalidValue;
 }
 
-static int g_impl = -1, g_impl_var = 0;  // -1: not decided yet (ESMK_GEMM_IMPL is read at the first launch)
+// Which persistent kernel serves a dense call.  g_impl: 8 = gemm8 always, 9 = gemm9 wherever it applies, 0 = auto:
+// gemm9 for the calls it measurably wins (profiles/r3_gemm9_schedC_variants.log: the long-K residual GEMM, fc2:
+// +6 %; the K = 1280 shapes lose their gain in the epilogue / seam), gemm8 otherwise.  Both give the same bits.
+// ESMK_GEMM_IMPL = 8 | 9 | 9:<variant> | auto;  ESMK_GEMM9_MASK = bit mask over epilogue codes for auto (default
+// 1 << EPI_RESID_F32), ESMK_GEMM9_MIN_K (default 2560).
+static int g_impl = -1, g_impl_var = 0, g_mask9 = 1 << EPI_RESID_F32, g_mink9 = 2560;
 void gemm_set_impl(int impl, int var) {
     g_impl = impl;
     g_impl_var = var;
@@ -570,16 +575,22 @@ void gemm_set_impl(int impl, int var) {
 hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipErrorInvalidValue;
     if (g_impl < 0) {
-        const char* e = getenv("ESMK_GEMM_IMPL");  // "9" or "9:<var>"
-        g_impl = (e != nullptr && e[0] == '9') ? 9 : 8;
+        const char* e = getenv("ESMK_GEMM_IMPL");
+        g_impl = (e != nullptr && e[0] == '9') ? 9 : (e != nullptr && e[0] == '8') ? 8 : 0;
         g_impl_var = (e != nullptr && e[0] == '9' && e[1] == ':') ? atoi(e + 2) : 0;
+        if (const char* m = getenv("ESMK_GEMM9_MASK")) g_mask9 = atoi(m);
+        if (const char* k = getenv("ESMK_GEMM9_MIN_K")) g_mink9 = atoi(k);
     }
-    if (g_impl == 9 && !p.force_old && !p.force_generic && !p.dbg && gemm9_supports(p, epi))
-        return launch_gemm9(p, epi, operand_dtype, g_impl_var, st);
     static const bool env_old = [] {
         const char* e = getenv("ESMK_GEMM");
         return e != nullptr && strcmp(e, "old") == 0;
     }();
+    if (!env_old && !p.force_old && !p.force_generic && !p.dbg && g_impl != 8 && gemm9_supports(p, epi)) {
+        if (g_impl == 9) return launch_gemm9(p, epi, operand_dtype, g_impl_var, st);
+        // auto: only launches that fill the chip for at least one round (small batches keep gemm8's half-height tiles)
+        const long long tiles = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+        if (((g_mask9 >> epi) & 1) && p.K >= g_mink9 && tiles >= 256) return launch_gemm9(p, epi, operand_dtype, 0, st);
+    }
     if (!env_old && !p.force_old && !p.force_generic && gemm8_supports(p, epi))
         return launch_gemm8(p, epi, operand_dtype, st);
     if (gemm8_generalised(p, epi)) return hipErrorInvalidValue;  // the tile kernels below only know dense calls

@@ -1,38 +1,45 @@
 // gemm9.hip — persistent nn.Linear for gfx950 with ONE wave per SIMD:
 //     C[M,N] = A[M,K] . W[N,K]^T (+ bias, + fused epilogue)          K % 64 == 0, N % 8 == 0, dense operands
 //
-// Same contract, tile order and epilogues as gemm8.hip (reference esm/multihead_attention.py:256-261,395;
+// Same contract, tile order and results as gemm8.hip (reference esm/multihead_attention.py:256-261,395;
 // esm/modules.py:138-139), different main loop.  gemm8 runs 8 waves (two per SIMD) on 128 x 64 wave blocks and
-// hides LDS / DMA latency by ping-pong between the two waves of a SIMD: 8 barriers per K tile, 24 KiB of
-// fragment reads per 32 MFMAs.  gemm9 runs 4 waves (one per SIMD, up to 512 registers each) on 128 x 128 wave
-// blocks of the same 256 x 256 x 64 tile:
-//   * fragment reads per MFMA drop by a third (32 KiB per 64 MFMAs per wave: 128 KiB instead of 192 KiB of
-//     LDS reads per K tile and CU);
-//   * ONE barrier per K tile: the wave's own instruction stream interleaves 64 MFMAs with 32 ds_read_b128
-//     (fragments of the next 16-wide K sub-step, double buffered in registers) and its 16 LDS-DMA pieces;
-//   * the 256 spare registers make the fp32 residual epilogue a deep software pipeline (8 pieces of the
-//     residual tile in flight instead of one: the epilogue was latency bound on those loads).
-// Every output element sees the same MFMA sequence over K as in gemm8 (bias enters as the C operand of the
-// first MFMA, then K ascending), so results are bit-identical to gemm8's.
+// hides LDS / DMA latency by ping-pong between the two waves of a SIMD: 8 barriers per K tile, 24 KiB of fragment
+// reads per 32 MFMAs.  gemm9 runs 4 waves (one per SIMD, 256 accumulator + 256 vector registers each) on 128 x 128
+// wave blocks of the same 256 x 256 x 64 tile:
+//   * fragment reads per MFMA drop by a third (32 KiB per 64 MFMAs per wave);
+//   * the wave's own instruction stream interleaves its 64 MFMAs with 32 ds_read_b128 and 16 LDS-DMA pieces, every
+//     MFMA gap carrying at most one read and one piece (pinned with sched_barrier: hipcc's own interleave bunches them);
+//   * TWO barriers per K tile, the LDS-DMA queue is never drained (counted vmcnt), a piece has 53 - 84 MFMA slots
+//     (~1 K tile) to land.
+// Every output element sees the same MFMA sequence over K as in gemm8 (bias enters as the C operand of the first
+// MFMA, then K ascending), so results are bit-identical to gemm8's (tools/bench_gemm9.py checks it on ragged shapes).
 //
-// LDS (160 KiB): two K-tile buffers of 64 KiB (A rows 0..255, then W rows 0..255; 128-byte rows, 16-byte
-// chunk index XOR-swizzled with (row >> 1) & 7 on the DMA source address and on the ds_read_b128), then
-// 4 x 8 KiB wave-private epilogue slices.  Wave w stages rows [128 w, 128 w + 128) of the buffer (waves 0,1:
-// activations, waves 2,3: weights) as 16 pieces of 8 rows; wave (wr, wc) = (w >> 1, w & 1) computes rows
-// [128 wr, +128) x columns [128 wc, +128) of the tile.
+// What was measured on the way (profiles/r3_gemm9_v1_*.log, one box, M = 65536): a first version with one barrier per
+// K tile and `vmcnt(0)` before it ran 3300 - 3500 cycles per K tile against gemm8's 2650 although its fragment reads
+// cost nothing (2200 cycles without the DMA): the 64 KiB of LDS-DMA per K tile and CU need ~1.6 us under full-chip load
+// whatever issues them, so a queue that is drained once per K tile idles half of the time.  Staging through registers
+// (global_load -> 64 VGPRs three positions ahead -> ds_write_b128) did not help (the ds_writes alone cost 340 cycles
+// per K tile).  The schedule below is the vendor asm kernel's idea (hipBLASLt MT256x256x64, one wave per SIMD, read
+// with llvm-objdump): hold the fragments of a WHOLE K tile in registers (128 VGPRs), read them early, so that the
+// LDS buffer of K tile s is free again a third into K tile s and the DMA of K tile s+2 streams into it while the
+// wait for K tile s+1 leaves the youngest pieces in flight.
 //
-// One K tile (stream position s, LDS buffer cur = s & 1), ks = 16-wide K sub-step, fragment sets alternate:
-//     ks 0   reads ks 1 -> set 1   DMA: second part of position s+1 -> cur^1      16 MFMA (set 0)
-//     ks 1   reads ks 2 -> set 0   [DMA: third part, schedule B]                  16 MFMA (set 1)
-//     ks 2   reads ks 3 -> set 1                                                  16 MFMA (set 0)
-//     s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier       (a) every wave's pieces of position s+1 have landed,
-//                                                    (b) every wave has finished reading buffer cur
-//     advance the DMA stream to position s+2
-//     ks 3   reads ks 0 of position s+1 (buffer cur^1) -> set 0
-//            DMA: first part of position s+2 -> cur                               16 MFMA (set 1)
-// The vmcnt(0) never waits for anything younger than 32 MFMA slots (schedule A: 8 + 8 pieces; schedule B
-// spreads them 6 + 5 + 5 and the youngest piece is 16 slots old).  The K tiles of all tiles of a workgroup
-// form one stream, as in gemm8: the first operands of the next tile land during the epilogue.
+// LDS (160 KiB): two K-tile buffers of 64 KiB (A rows 0..255, then W rows 0..255; 128-byte rows, 16-byte chunk index
+// XOR-swizzled with (row >> 1) & 7 on the DMA source address and on the ds_read_b128), then 4 x 8 KiB wave-private
+// epilogue slices.  Wave w stages rows [64 w, 64 w + 64) of the A panel and of the W panel (8 + 8 pieces of 8 rows,
+// `buffer_load ... lds`: rows past the end of the operand are out of the descriptor's range and arrive as zeros);
+// wave (wr, wc) = (w >> 1, w & 1) computes rows [128 wr, +128) x columns [128 wc, +128) of the tile.
+//
+// One K tile (stream position s, LDS buffer cur = s & 1), MFMA slots m = 0..63 (m = 32 half + 16 ks + 4 j + i;
+// X = fragments of K 0..31, Y = fragments of K 32..63 of the tile):
+//     m  0..15   ds_read: Y fragments of position s (buffer cur) — X of position s was read during position s-1
+//     m 18       s_waitcnt lgkmcnt(0); s_barrier        every wave has read buffer cur completely
+//     m 18..48   LDS-DMA: the 16 pieces of position s+2 -> buffer cur, one every other slot
+//     m 46       s_waitcnt vmcnt(14); s_barrier         every wave's pieces of position s+1 have landed (the 14
+//                                                       youngest pieces, of position s+2, stay in flight)
+//     m 46..61   ds_read: X fragments of position s+1 (buffer cur^1)
+// The K tiles of all tiles of a workgroup form one stream, as in gemm8: the first operands of the next tile land
+// during the epilogue.
 #include "gemm_epi.h"
 #include <stdlib.h>
 #include <string.h>
@@ -46,12 +53,17 @@ constexpr int Q_EPI = 2 * Q_BUF;             // wave-private epilogue slices
 constexpr int Q_SLICE = 8192;
 constexpr int Q_LDS = Q_EPI + 4 * Q_SLICE;   // 160 KiB
 
+#define ESMK_INL __attribute__((always_inline))
+
 // --------------------------------------------------------------------------------------------
-// fp32 epilogue of the wave's 128 x 128 block: 16 pieces of 32 rows x 32 columns through the wave's LDS
-// slice (every global access covers whole 128-byte row segments).  EPI_RESID_F32 keeps D pieces of the
-// residual tile in flight.  Same arithmetic as epilogue8 (old + value), so bit-identical results.
+// Epilogues of the wave's 128 x 128 block.  The accumulators live in AGPRs; ds_write_b128 takes them from there, so
+// every epilogue writes fp32 quads straight into the wave's LDS slice and does its arithmetic on the transposed
+// (row-major) read — no v_accvgpr_read pass, few live VGPRs.
+// acc[hf][j2][i][r]:  m = m_base + 32 i + (lane & 31);  n = n_base + 64 hf + 32 j2 + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)
 // --------------------------------------------------------------------------------------------
-template <typename T, int EPI, bool FULL, int D = 8>
+// fp32 outputs: 16 pieces of 32 rows x 32 columns (128-byte row segments).  EPI_RESID_F32 keeps D pieces of the
+// residual tile in flight.  Same arithmetic as epilogue8 (old + value).
+template <typename T, int EPI, bool FULL, int D = 4>
 ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x16 (&acc)[2][2][4], int m_base, int n_base, int lane, char* wl) {
     if constexpr (!FULL)
         if (n_base >= p.N || m_base >= p.M) return;  // wave uniform
@@ -59,7 +71,7 @@ ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x16 (&acc)[2][2][4], int m_bas
     const int ldc = p.N;
     const int h = lane >> 5, lm = lane & 31;
     f32x4 old[D][4];
-    auto load_old = [&](f32x4 (&dst)[4], int piece) __attribute__((always_inline)) {
+    auto load_old = [&](f32x4 (&dst)[4], int piece) ESMK_INL {
         const int i = piece >> 2, jb = piece & 3;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -109,25 +121,116 @@ ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x16 (&acc)[2][2][4], int m_bas
     }
 }
 
+// operand-dtype outputs (EPI_STORE_T, EPI_GELU_T, EPI_QKV_ROPE): 8 rounds of 32 rows x 64 columns.  A round's 8 KiB
+// fp32 image has 256-byte rows, 16-byte chunk c of row r at slot c ^ (r & 7): conflict free for the quad writes
+// (8 lanes = 8 rows of one chunk) and for the row-major reads (16 lanes = 16 different chunks).
+template <typename T, int EPI, bool FULL>
+ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x16 (&acc)[2][2][4], int m_base, int n_base, int lane, char* wl) {
+    using V8 = typename Op<T>::v8;
+    const int h = lane >> 5, lm = lane & 31;
+    if constexpr (!FULL)
+        if (m_base >= p.M) return;  // wave uniform
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int nb = n_base + 64 * hf;
+        if constexpr (!FULL)
+            if (nb >= p.N) continue;  // wave uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int chunk = 8 * j2 + 2 * g + h;
+                    *reinterpret_cast<f32x4*>(wl + lm * 256 + ((chunk ^ (lm & 7)) << 4)) =
+                        f32x4{acc[hf][j2][i][4 * g], acc[hf][j2][i][4 * g + 1], acc[hf][j2][i][4 * g + 2], acc[hf][j2][i][4 * g + 3]};
+                }
+            if constexpr (EPI == EPI_QKV_ROPE) {
+                // the 64 columns are one head (head_dim 64): dims d and d + 32 rotate together
+                // (multihead_attention.py:261 q scaling, rotary_embedding.py:11-20 x*cos + rotate_half(x)*sin)
+                const int which = nb / p.E;  // 0 q, 1 k (wave uniform)
+                const int head = (nb - which * p.E) >> 6;
+                T* qk = reinterpret_cast<T*>(which == 0 ? p.q : p.k);
+                const float sc = which == 0 ? p.scaling : 1.0f;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int slot = it * 64 + lane;
+                    const int r = slot >> 2, g4 = slot & 3;  // row of the round, dims [8 g4, 8 g4 + 8)
+                    float a1[8], a2[8];
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((2 * g4 + e2) ^ (r & 7)) << 4));
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((8 + 2 * g4 + e2) ^ (r & 7)) << 4));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a1[4 * e2 + e] = u[e], a2[4 * e2 + e] = w[e];
+                    }
+                    const int mm = m_base + 32 * i + r;
+                    const int m = FULL ? mm : min(mm, p.M - 1);
+                    const int b = m / p.T, tt = m - b * p.T;
+                    float y1[8], y2[8];
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const f32x4 c = *reinterpret_cast<const f32x4*>(p.cos + (size_t)tt * 32 + 8 * g4 + 4 * e2);
+                        const f32x4 s = *reinterpret_cast<const f32x4*>(p.sin + (size_t)tt * 32 + 8 * g4 + 4 * e2);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x1 = a1[4 * e2 + e] * sc;
+                            const float x2 = a2[4 * e2 + e] * sc;
+                            y1[4 * e2 + e] = x1 * c[e] - x2 * s[e];
+                            y2[4 * e2 + e] = x2 * c[e] + x1 * s[e];
+                        }
+                    }
+                    V8 o1, o2;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o1[e] = Op<T>::from(y1[e]), o2[e] = Op<T>::from(y2[e]);
+                    if (FULL || mm < p.M) {
+                        T* dst = qk + ((size_t)(b * p.H + head) * p.T + tt) * 64 + 8 * g4;
+                        *reinterpret_cast<V8*>(dst) = o1;
+                        *reinterpret_cast<V8*>(dst + 32) = o2;
+                    }
+                }
+            } else {
+                T* out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int slot = it * 64 + lane;
+                    const int r = slot >> 3, c8 = slot & 7;  // row of the round, columns [8 c8, 8 c8 + 8)
+                    float v[8];
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((2 * c8 + e2) ^ (r & 7)) << 4));
+                        float t4[4] = {u[0], u[1], u[2], u[3]};
+                        if constexpr (EPI == EPI_GELU_T) gelu_fast_x4(t4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * e2 + e] = t4[e];
+                    }
+                    V8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = Op<T>::from(v[e]);
+                    const int m = m_base + 32 * i + r, n = nb + 8 * c8;
+                    if (FULL || (m < p.M && n < p.N)) *reinterpret_cast<V8*>(out + (size_t)m * p.N + n) = o;
+                }
+            }
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------------
-// kernel.  VAR bit 0: DMA schedule B (6 + 5 + 5 pieces over ks 3 / 0 / 1 instead of 8 + 8 over ks 3 / 0);
-// bit 2 (4): REGISTER STAGING instead of LDS-DMA — the wave's 16 pieces of a stream position are fetched with
-// global_load_dwordx4 into 64 VGPRs THREE positions ahead (two register sets = two positions in flight besides the
-// two LDS buffers) and written to the LDS with ds_write_b128 one position ahead.  Measured motive
-// (profiles/r3_gemm9_first_call.log): with LDS-DMA the loop is bound by (bytes in flight) / (loaded fabric latency) —
-// the landing space is the LDS itself, so at most one K tile per wave can be in flight and every vmcnt wait sits
-// behind an L2 miss; registers double the bytes in flight.  Needs an even number of K tiles (static set index).
-// bits 4.. = DBG timing experiments (results are wrong): 16 no MFMA, 32 no staging loads, 64 no fragment reads,
+// kernel.  VAR = timing experiments (results are wrong): 16 no MFMA, 32 no LDS-DMA, 64 no fragment reads,
 // 128 no epilogue.
 // --------------------------------------------------------------------------------------------
 template <typename T, int EPI, int VAR = 0>
 __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long long* timing) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V8 = typename Op<T>::v8;
-    constexpr bool SCHED_B = (VAR & 1) != 0, REGST = (VAR & 4) != 0;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
     constexpr bool NO_MFMA = (VAR & 16) != 0, NO_DMA = (VAR & 32) != 0, NO_RD = (VAR & 64) != 0, NO_EPI = (VAR & 128) != 0;
-    constexpr int Q3 = SCHED_B ? 6 : 8;    // pieces issued in ks 3 (first part of a position)
-    constexpr int Q0 = SCHED_B ? 11 : 16;  // ks 0 issues [Q3, Q0), ks 1 issues [Q0, 16)
+    // slots of the two barriers (VAR & 3: placement experiments; VAR & 8: without the s_barrier, results wrong)
+    // measured (profiles/r3_gemm9_schedC_variants.log): 18/46 beats 20/40, 16/36 and 24/44 on all four layer shapes
+    constexpr int M_B1 = (VAR & 3) == 1 ? 16 : (VAR & 3) == 2 ? 24 : (VAR & 3) == 3 ? 20 : 18;
+    constexpr int M_B2 = (VAR & 3) == 1 ? 36 : (VAR & 3) == 2 ? 52 : (VAR & 3) == 3 ? 40 : 46;
+    constexpr bool NO_BAR = (VAR & 8) != 0;
+    constexpr int IN_FLIGHT = (M_B2 - M_B1 + 1) / 2 > 16 ? 16 : (M_B2 - M_B1 + 1) / 2;  // pieces of position s+2 issued before the second barrier
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -146,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     if (n_my == 0) return;
     const int panel_c = p.panel_c > 0 ? p.panel_c : tiles_n;
     const int panel_full = tiles_m * panel_c;
-    auto tile_coords = [&](int it, int& tmi, int& tni) __attribute__((always_inline)) {
+    auto tile_coords = [&](int it, int& tmi, int& tni) ESMK_INL {
         const int o = start + slot + it * nslot;
         const int pnl = o / panel_full;
         const int rem = o - pnl * panel_full;
@@ -155,68 +258,56 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
         tni = __builtin_amdgcn_readfirstlane(pnl * panel_c + (rem - tmi * w));
     };
 
-    // ---- LDS-DMA stream of this wave: 16 pieces of 8 rows per stream position -------------------------------
-    // The stream state is scalar (operand panel + K offset, last valid row of the panel, position); a piece's
-    // per-lane source offset is recomputed when it is issued (3 VALU instructions beside the MFMAs): lane l of
-    // piece q fetches 16-byte chunk (l & 7) ^ swizzle(row) of row min(srow0 + 8 q + l / 8, lim).
-    const bool is_a = wave < 2;
-    const int srow0 = (wave & 1) * 128;  // first of the wave's 128 rows inside the tile's operand panel
-    const char* s_base;                  // operand panel of the stream's tile + K offset (wave uniform)
-    int s_kt, s_it, s_lim;
-    const int rl = srow0 + (lane >> 3);
-    // (row >> 1) & 7 of row = srow0 + 8 q + lane / 8:  4 (q & 1) + ((lane >> 4) & 3)
-    const unsigned ch_even = (unsigned)(((lane & 7) ^ ((lane >> 4) & 3)) << 4);
-    const unsigned ch_odd = (unsigned)(((lane & 7) ^ (4 + ((lane >> 4) & 3))) << 4);
-    auto set_tile = [&](int it) __attribute__((always_inline)) {
+    // ---- LDS-DMA stream of this wave: 8 + 8 pieces of 8 rows per stream position --------------------------------
+    // Scalar state only: one buffer descriptor per operand (base = the tile's panel, num_records = its valid rows), the
+    // K offset and the position.  Piece q: per-lane offset (64 wave + lane / 8) rb + swizzled chunk (two registers:
+    // the swizzle alternates with q), scalar offset 8 q rb + K offset.
+    auto uniform_ptr = [](const void* ptr) ESMK_INL {
+        const unsigned long long a = (unsigned long long)ptr;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return (void*)(((unsigned long long)hi << 32) | lo);
+    };
+    __amdgpu_buffer_rsrc_t d_a, d_w;
+    int s_kt, s_it;
+    unsigned s_koff;
+    const unsigned rb8 = 8u * rb;
+    // (row >> 1) & 7 of row = 64 wave + 8 q + lane / 8:  4 (q & 1) + ((lane >> 4) & 3)
+    const unsigned vo_base = (unsigned)(64 * wave + (lane >> 3)) * rb;
+    const unsigned vo_even = vo_base + (unsigned)(((lane & 7) ^ ((lane >> 4) & 3)) << 4);
+    const unsigned vo_odd = vo_base + (unsigned)(((lane & 7) ^ (4 + ((lane >> 4) & 3))) << 4);
+    auto set_tile = [&](int it) ESMK_INL {
         int tmi, tni;
         tile_coords(it, tmi, tni);
         s_it = it;
         s_kt = 0;
-        s_lim = is_a ? p.M - tmi * 256 - 1 : p.N - tni * 256 - 1;
-        s_base = is_a ? reinterpret_cast<const char*>(p.A) + (size_t)tmi * 256 * rb
-                      : reinterpret_cast<const char*>(p.W) + (size_t)tni * 256 * rb;
+        s_koff = 0;
+        const unsigned rows_a = (unsigned)min(256, p.M - tmi * 256), rows_w = (unsigned)min(256, p.N - tni * 256);
+        d_a = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(reinterpret_cast<const char*>(p.A) + (size_t)tmi * 256 * rb), 0,
+                                                (int)__builtin_amdgcn_readfirstlane(rows_a * rb), 0x00020000);
+        d_w = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(reinterpret_cast<const char*>(p.W) + (size_t)tni * 256 * rb), 0,
+                                                (int)__builtin_amdgcn_readfirstlane(rows_w * rb), 0x00020000);
     };
-    auto advance = [&]() __attribute__((always_inline)) {
+    auto advance = [&]() ESMK_INL {
         // past the end of the workgroup's tile list the last K tile is re-issued (into a dead buffer), so the
         // wait bookkeeping stays uniform
         if (s_kt + 1 < nk) {
             s_kt = s_kt + 1;
-            s_base += 128;
+            s_koff += 128u;
         } else if (s_it + 1 < n_my) {
             set_tile(s_it + 1);
         }
     };
-    // (loop-invariant rl + 8 q would be hoisted into 16 registers: the add stays beside its load)
-    auto opaque = [](int v) __attribute__((always_inline)) {
-        asm volatile("" : "+v"(v));
-        return v;
-    };
-    auto issue1 = [&](int q, int buf) __attribute__((always_inline)) {  // q: compile-time constant after unrolling
+    // piece k = 0..15: operand k & 1 (0 activations, 1 weights), rows 8 (k >> 1) .. of the wave's 64
+    auto issue1 = [&](int k, int buf) ESMK_INL {
         if constexpr (!NO_DMA) {
-            const unsigned row = (unsigned)min(opaque(rl) + 8 * q, s_lim);
-            const unsigned o = __umul24(row, rb) + ((q & 1) ? ch_odd : ch_even);  // row, rb < 2^24
-            glds16(s_base + o, smem + buf * Q_BUF + wave * 16384 + q * 1024);
+            const int q = k >> 1;
+            char* dst = smem + buf * Q_BUF + ((k & 1) ? Q_WOFF : 0) + wave * 8192 + q * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds((k & 1) ? d_w : d_a, (lds_ptr)dst, 16, (q & 1) ? vo_odd : vo_even,
+                                                     s_koff + (unsigned)q * rb8, 0, 0);
         }
-    };
-#define ESMK_ISSUE(QA, QB, BUF) \
-    { _Pragma("unroll") for (int q_ = (QA); q_ < (QB); ++q_) issue1(q_, (BUF)); }
-    // register staging (REGST): piece q of the stream's position -> G[set][q]; G[set][q] -> its LDS slot
-    f32x4 G[2][16];
-    auto gload = [&](int set, int q) __attribute__((always_inline)) {
-        if constexpr (!NO_DMA) {
-            const unsigned row = (unsigned)min(opaque(rl) + 8 * q, s_lim);
-            const unsigned o = __umul24(row, rb) + ((q & 1) ? ch_odd : ch_even);
-            G[set][q] = *reinterpret_cast<const f32x4*>(s_base + o);
-        } else {
-            G[set][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    const int lds_lane = wave * 16384 + lane * 16;
-    auto lwrite = [&](int set, int q, int buf) __attribute__((always_inline)) {
-        *reinterpret_cast<f32x4*>(smem + buf * Q_BUF + lds_lane + q * 1024) = G[set][q];
     };
 
-    // ---- fragment reads ----------------------------------------------------------------------------------------
+    // ---- fragments: X = K 0..31, Y = K 32..63 of a K tile; [ks & 1][32-row block] --------------------------------
     const int lrow = (lane & 31) * 128;
     const int swz = (lane >> 1) & 7;
     int xo[4];
@@ -224,165 +315,131 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     for (int ks = 0; ks < 4; ++ks) xo[ks] = ((2 * ks + (lane >> 5)) ^ swz) << 4;
     const int a_off = wr * 16384 + lrow;
     const int w_off = Q_WOFF + wc * 16384 + lrow;
-    V8 fa[2][4], fw[2][4];
+    V8 xa[2][4], xw[2][4], ya[2][4], yw[2][4];
     if constexpr (NO_RD) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) fa[s][i][e] = fw[s][i][e] = Op<T>::from(0.f);
+                for (int e = 0; e < 8; ++e) xa[s][i][e] = xw[s][i][e] = ya[s][i][e] = yw[s][i][e] = Op<T>::from(0.f);
     }
-    // one fragment of K sub-step ks from buffer `bp`: r even -> activation rows 32 (r/2) .., r odd -> weight rows 32 (r/2) ..
-    auto rd1 = [&](V8 (&a)[4], V8 (&w)[4], const char* bp, int ks, int r) __attribute__((always_inline)) {
+    // read r = 0..15 of a half: K sub-step 2 half + (r >> 3), block (r >> 1) & 3, r even -> activations, odd -> weights
+    auto rd1 = [&](V8 (&fa)[2][4], V8 (&fw)[2][4], const char* bp, int half, int r) ESMK_INL {
         if constexpr (!NO_RD) {
-            if (r & 1) w[r >> 1] = *reinterpret_cast<const V8*>(bp + w_off + (r >> 1) * 4096 + xo[ks]);
-            else a[r >> 1] = *reinterpret_cast<const V8*>(bp + a_off + (r >> 1) * 4096 + xo[ks]);
+            const int k2 = r >> 3, blk = (r >> 1) & 3;
+            if (r & 1) fw[k2][blk] = *reinterpret_cast<const V8*>(bp + w_off + blk * 4096 + xo[2 * half + k2]);
+            else fa[k2][blk] = *reinterpret_cast<const V8*>(bp + a_off + blk * 4096 + xo[2 * half + k2]);
         }
     };
 
     f32x16 acc[2][2][4];  // [64-column half][32-column block][32-row block]
-    // bias broadcast of 32-column block j (the C operand of a tile's first MFMAs: acc = bias + A.W^T, the order gemm8
-    // uses).  Column n = n_base + 32 j + 8 (r >> 2) + 4 (lane >> 5) + (r & 3) sits in register r.  Scalar loads through
+    // bv[j]: bias broadcast of 32-column block j (the C operand of a tile's first MFMAs: acc = bias + A.W^T, the order
+    // gemm8 uses).  Column n = n_base + 32 j + 8 (r >> 2) + 4 (lane >> 5) + (r & 3) sits in register r.  Scalar loads through
     // the constant address space: they do not enter the vmcnt queue.  EPI_V_T: the bias varies with the lane, its
     // epilogue adds it.
     typedef const __attribute__((address_space(4))) float* cfloat_ptr;
-    int bias_n0 = 0;  // n_base of the current tile
-    auto bias_vec = [&](int j) __attribute__((always_inline)) {
-        f32x16 b;
+    f32x16 bv[4];
+    auto init_bias = [&](int n_base) ESMK_INL {
         bool done = false;
         if constexpr (EPI != EPI_V_T) {
             if (p.bias != nullptr) {
                 const int hsel = lane >> 5;
-                if (bias_n0 + 128 <= p.N) {
-                    cfloat_ptr cb = (cfloat_ptr)(unsigned long long)(p.bias + bias_n0 + 32 * j);
+                if (n_base + 128 <= p.N) {
+                    cfloat_ptr cb = (cfloat_ptr)(unsigned long long)(p.bias + n_base);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float b0 = cb[8 * (r >> 2) + (r & 3)], b1 = cb[8 * (r >> 2) + 4 + (r & 3)];
-                        b[r] = hsel ? b1 : b0;
-                    }
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float b0 = cb[32 * j + 8 * g + e], b1 = cb[32 * j + 8 * g + 4 + e];
+                                bv[j][4 * g + e] = hsel ? b1 : b0;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);  // 8 SGPRs at a time
+                        }
                 } else {  // N tail: clamped vector loads
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int n = bias_n0 + 32 * j + 8 * (r >> 2) + 4 * hsel + (r & 3);
-                        b[r] = n < p.N ? p.bias[n] : 0.f;
-                    }
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int n = n_base + 32 * j + 8 * (r >> 2) + 4 * hsel + (r & 3);
+                            bv[j][r] = n < p.N ? p.bias[n] : 0.f;
+                        }
                 }
                 done = true;
             }
         }
         if (!done) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) b[r] = 0.f;
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bv[j][r] = 0.f;
         }
-        return b;
     };
-    // MFMA t of a 16-wide K sub-step (16 MFMAs, every accumulator once: column block j = t / 4, row block i = t & 3).
-    // first: the tile's first sub-step, C operand = bias broadcast bj.
-    auto mma1 = [&](const V8 (&a)[4], const V8 (&w)[4], int t, bool first, const f32x16& bj) __attribute__((always_inline)) {
-        const int j = t >> 2, i = t & 3;
+    // MFMA of slot m: K sub-step (m >> 4), column block j = (m >> 2) & 3, row block i = m & 3
+    auto mma1 = [&](const V8 (&fa)[2][4], const V8 (&fw)[2][4], int m, bool first) ESMK_INL {
+        const int k2 = (m >> 4) & 1, j = (m >> 2) & 3, i = m & 3;
         f32x16& c = acc[j >> 1][j & 1][i];
+        const bool use_b = first && m < 16;  // the tile's first sub-step: C operand = bias broadcast
         if constexpr (NO_MFMA) {
-            asm volatile("" ::"v"(a[i]), "v"(w[j]));
-            if (first) c = bj;
+            asm volatile("" ::"v"(fa[k2][i]), "v"(fw[k2][j]));
+            if (use_b) c = bv[j];
         } else if constexpr (EPI == EPI_V_T) {  // lane owns 4 consecutive tokens of one channel
-            c = first ? Op<T>::mma(a[i], w[j], bj) : Op<T>::mma(a[i], w[j], c);
+            c = use_b ? Op<T>::mma(fa[k2][i], fw[k2][j], bv[j]) : Op<T>::mma(fa[k2][i], fw[k2][j], c);
         } else {  // lane owns 4 consecutive channels of one token
-            c = first ? Op<T>::mma(w[j], a[i], bj) : Op<T>::mma(w[j], a[i], c);
+            c = use_b ? Op<T>::mma(fw[k2][j], fa[k2][i], bv[j]) : Op<T>::mma(fw[k2][j], fa[k2][i], c);
         }
     };
 
     int cur = 0;
-    // One 16-wide K sub-step as 16 pinned micro-steps of one MFMA: steps 0-7 also read one fragment of the NEXT
-    // sub-step (>= 8 MFMA slots to land before that sub-step starts), steps 8-15 issue this sub-step's LDS-DMA
-    // pieces [qa, qb) into buffer dbuf, evenly spread.  (hipcc's own interleave of the 16 + 8 + 8 instructions
-    // bunched the reads and DMA pieces; sched_group_barrier did not separate the DMA instructions.)
-    // REGST: steps 8-15 instead move pieces [qa, qb): G[gset][q] -> LDS buffer dbuf (position s+1), then refill
-    // G[gset][q] from the stream (position s+3).
-    auto substep = [&](const V8 (&a)[4], const V8 (&w)[4], V8 (&na)[4], V8 (&nw)[4], const char* nbuf, int nks,
-                       int qa, int qb, int dbuf, bool first, int gset = 0) __attribute__((always_inline)) {
-        f32x16 bj;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            if (first && (t & 3) == 0) bj = bias_vec(t >> 2);
-            mma1(a, w, t, first, bj);
-            if (t < 8) {
-                rd1(na, nw, nbuf, nks, t);
-            } else {
-                const int cntq = qb - qa;
-#pragma unroll
-                for (int k = 0; k < cntq; ++k)
-                    if (8 + (k * 8) / cntq == t) {
-                        if constexpr (REGST) {
-                            lwrite(gset, qa + k, dbuf);
-                            gload(gset, qa + k);
-                        } else {
-                            issue1(qa + k, dbuf);
-                        }
-                    }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // par: parity of the stream position (REGST: position s moves register set par ^ 1)
-    auto ktile = [&](bool first, int par) __attribute__((always_inline)) {
+    auto ktile = [&](bool first) ESMK_INL {
         const char* sb = smem + cur * Q_BUF;
         const char* sn = smem + (cur ^ 1) * Q_BUF;
-        if constexpr (REGST) {
-            // position s+1: registers -> buffer cur^1 (free since the barrier of position s-1); refill with s+3
-            substep(fa[0], fw[0], fa[1], fw[1], sb, 1, 0, 6, cur ^ 1, first, par ^ 1);    // ks 0
-            substep(fa[1], fw[1], fa[0], fw[0], sb, 2, 6, 11, cur ^ 1, false, par ^ 1);   // ks 1
-            substep(fa[0], fw[0], fa[1], fw[1], sb, 3, 11, 16, cur ^ 1, false, par ^ 1);  // ks 2
-            // every wave's LDS writes of position s+1 are done, every wave is done reading buffer cur; the global
-            // loads stay in flight (hipcc counts them: a ds_write waits for exactly its own load)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        advance();  // the stream now stands at position s+2
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 64; ++m) {
+            if (m == M_B1) {  // every wave has read buffer cur completely
+                if constexpr (NO_BAR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (m == M_B2) {  // every wave's pieces of position s+1 have landed; IN_FLIGHT younger ones stay in flight
+                if constexpr (NO_BAR) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_FLIGHT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(IN_FLIGHT) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (m < 32) mma1(xa, xw, m, first);
+            else mma1(ya, yw, m, first);
+            if (m < 16) rd1(ya, yw, sb, 1, m);
+            if (m >= M_B1 && m < M_B1 + 32 && ((m - M_B1) & 1) == 0) issue1((m - M_B1) >> 1, cur);
+            if constexpr (M_B2 + 16 <= 64) {
+                if (m >= M_B2 && m < M_B2 + 16) rd1(xa, xw, sn, 0, m - M_B2);
+            } else {  // late second barrier: two reads per slot
+                if (m >= M_B2 && m < M_B2 + 8) {
+                    rd1(xa, xw, sn, 0, 2 * (m - M_B2));
+                    rd1(xa, xw, sn, 0, 2 * (m - M_B2) + 1);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
-            advance();
-            __builtin_amdgcn_sched_barrier(0);
-            substep(fa[1], fw[1], fa[0], fw[0], sn, 0, 0, 0, cur, false);                 // ks 3
-        } else {
-            substep(fa[0], fw[0], fa[1], fw[1], sb, 1, Q3, Q0, cur ^ 1, first);   // ks 0
-            substep(fa[1], fw[1], fa[0], fw[0], sb, 2, Q0, 16, cur ^ 1, false);   // ks 1
-            substep(fa[0], fw[0], fa[1], fw[1], sb, 3, 0, 0, cur, false);         // ks 2
-            // every wave's pieces of position s+1 have landed, every wave is done reading buffer cur
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            advance();
-            __builtin_amdgcn_sched_barrier(0);
-            substep(fa[1], fw[1], fa[0], fw[0], sn, 0, 0, Q3, cur, false);        // ks 3
         }
         cur ^= 1;
     };
 
-    // ---- prologue: position 0 completely, the first part of position 1 ----------------------------------------
+    // ---- prologue: positions 0 and 1 on their way, X fragments of position 0 in registers -------------------------
     set_tile(0);
-    if constexpr (REGST) {
-        // positions 0, 1 -> G[0], G[1]; position 0 -> LDS buffer 0; position 2 -> G[0]; the stream stands at position 3
 #pragma unroll
-        for (int q = 0; q < 16; ++q) gload(0, q);
-        advance();
+    for (int k = 0; k < 16; ++k) issue1(k, 0);
+    advance();
 #pragma unroll
-        for (int q = 0; q < 16; ++q) gload(1, q);
-        advance();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            lwrite(0, q, 0);
-            gload(0, q);
-        }
-        advance();
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    } else {
-        ESMK_ISSUE(0, 16, 0)
-        advance();
-        ESMK_ISSUE(0, Q3, 1)
-        if constexpr (SCHED_B) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-    }
+    for (int k = 0; k < 16; ++k) issue1(k, 1);
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) rd1(fa[0], fw[0], smem, 0, r);
+    for (int r = 0; r < 16; ++r) rd1(xa, xw, smem, 0, r);
 
-    auto stamp = [&](int it, int k) __attribute__((always_inline)) {
+    auto stamp = [&](int it, int k) ESMK_INL {
         if (timing != nullptr && tid == 0) {
             unsigned long long* t = timing + ((size_t)blockIdx.x * 32 + (it & 31)) * 4;
             t[k] = __builtin_readcyclecounter();
@@ -394,44 +451,35 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
         int tmi, tni;
         tile_coords(it, tmi, tni);
         const int m_base = tmi * 256 + wr * 128, n_base = tni * 256 + wc * 128;
-        bias_n0 = n_base;
+        init_bias(n_base);
         stamp(it, 0);
-        if constexpr (REGST) {  // nk is even: static register-set index
-            ktile(true, 0);
-            ktile(false, 1);
+        ktile(true);
 #pragma unroll 1
-            for (int kt = 2; kt < nk; kt += 2) {
-                ktile(false, 0);
-                ktile(false, 1);
-            }
-        } else {
-            ktile(true, 0);
-#pragma unroll 1
-            for (int kt = 1; kt < nk; ++kt) ktile(false, 0);
-        }
+        for (int kt = 1; kt < nk; ++kt) ktile(false);
         stamp(it, 1);
         char* slice = smem + Q_EPI + wave * Q_SLICE;
+        const bool full = (m_base + 128 <= p.M) && (n_base + 128 <= p.N);
         if constexpr (NO_EPI) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[hf][j][i]));
+                    for (int i = 0; i < 4; ++i) asm volatile("" ::"a"(acc[hf][j][i]));
         } else if constexpr (EPI == EPI_STORE_F32 || EPI == EPI_GELU_F32 || EPI == EPI_RESID_F32) {
-            const bool full = (m_base + 128 <= p.M) && (n_base + 128 <= p.N);
-            constexpr int D = REGST ? 3 : 8;  // REGST keeps 128 staging registers live across the epilogue
-            if (full) epilogue9_f32<T, EPI, true, D>(p, acc, m_base, n_base, lane, slice);
-            else epilogue9_f32<T, EPI, false, D>(p, acc, m_base, n_base, lane, slice);
-        } else {
+            if (full) epilogue9_f32<T, EPI, true>(p, acc, m_base, n_base, lane, slice);
+            else epilogue9_f32<T, EPI, false>(p, acc, m_base, n_base, lane, slice);
+        } else if constexpr (EPI == EPI_V_T) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int nb = n_base + 64 * hf;
-                bool full = (m_base + 128 <= p.M) && (nb + 64 <= p.N);
-                if constexpr (EPI == EPI_V_T) full = full && (p.T % 32 == 0);
-                if (full) epilogue8<T, EPI, true, false, false, 4>(p, acc[hf], m_base, nb, lane, slice + hf * 4096, 0, 0, 0);
+                const bool f2 = (m_base + 128 <= p.M) && (nb + 64 <= p.N) && (p.T % 32 == 0);
+                if (f2) epilogue8<T, EPI, true, false, false, 4>(p, acc[hf], m_base, nb, lane, slice + hf * 4096, 0, 0, 0);
                 else epilogue8<T, EPI, false, false, false, 4>(p, acc[hf], m_base, nb, lane, slice + hf * 4096, 0, 0, 0);
             }
+        } else {
+            if (full) epilogue9_t<T, EPI, true>(p, acc, m_base, n_base, lane, slice);
+            else epilogue9_t<T, EPI, false>(p, acc, m_base, n_base, lane, slice);
         }
         stamp(it, 2);
     }
@@ -482,32 +530,30 @@ bool gemm9_supports(const GemmArgs& p, int epi) {
     if (p.K % 64 != 0 || p.N % 8 != 0 || p.M <= 0) return false;
     if (gemm8_generalised(p, epi) || p.half_m > 0) return false;
     if ((epi == EPI_QKV_ROPE || epi == EPI_V_T) && p.N % 64 != 0) return false;
+    if ((long long)256 * p.K * 2 > 0x7fffffffLL) return false;  // a panel must fit a buffer descriptor
     return epi >= EPI_STORE_T && epi <= EPI_V_T;
 }
 
 template <typename T>
 static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st) {
-#define ESMK_CASES9(V)                                                      \
-    switch (epi) {                                                          \
-        case EPI_STORE_T: return launch9<T, EPI_STORE_T, V>(p, st);         \
-        case EPI_STORE_F32: return launch9<T, EPI_STORE_F32, V>(p, st);     \
-        case EPI_GELU_T: return launch9<T, EPI_GELU_T, V>(p, st);           \
-        case EPI_GELU_F32: return launch9<T, EPI_GELU_F32, V>(p, st);       \
-        case EPI_RESID_F32: return launch9<T, EPI_RESID_F32, V>(p, st);     \
-        case EPI_QKV_ROPE: return launch9<T, EPI_QKV_ROPE, V>(p, st);       \
-        case EPI_V_T: return launch9<T, EPI_V_T, V>(p, st);                 \
-    }
-    if (var == 0) { ESMK_CASES9(0) }
-    if (var == 1) { ESMK_CASES9(1) }
-    if (var == 4) {
-        if ((p.K / 64) % 2 != 0) return hipErrorInvalidValue;  // register staging: even number of K tiles
-        ESMK_CASES9(4)
+    if (var == 0) {
+        switch (epi) {
+            case EPI_STORE_T: return launch9<T, EPI_STORE_T>(p, st);
+            case EPI_STORE_F32: return launch9<T, EPI_STORE_F32>(p, st);
+            case EPI_GELU_T: return launch9<T, EPI_GELU_T>(p, st);
+            case EPI_GELU_F32: return launch9<T, EPI_GELU_F32>(p, st);
+            case EPI_RESID_F32: return launch9<T, EPI_RESID_F32>(p, st);
+            case EPI_QKV_ROPE: return launch9<T, EPI_QKV_ROPE>(p, st);
+            case EPI_V_T: return launch9<T, EPI_V_T>(p, st);
+        }
     }
     if constexpr (std::is_same<T, _Float16>::value) {
-        // measurement variants (tools/bench_gemm9.py): plain-store / residual epilogues only
-        if (epi == EPI_STORE_T) {
+        if (epi == EPI_STORE_T) {  // timing experiments (tools/bench_gemm9.py --dbg)
             switch (var) {
-                case 36: return launch9<T, EPI_STORE_T, 36>(p, st);  // register staging without its loads
+                case 1: return launch9<T, EPI_STORE_T, 1>(p, st);
+                case 2: return launch9<T, EPI_STORE_T, 2>(p, st);
+                case 3: return launch9<T, EPI_STORE_T, 3>(p, st);
+                case 8: return launch9<T, EPI_STORE_T, 8>(p, st);
                 case 16: return launch9<T, EPI_STORE_T, 16>(p, st);
                 case 32: return launch9<T, EPI_STORE_T, 32>(p, st);
                 case 64: return launch9<T, EPI_STORE_T, 64>(p, st);
@@ -517,7 +563,6 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
             }
         }
     }
-#undef ESMK_CASES9
     return hipErrorInvalidValue;
 }
 

@@ -214,9 +214,10 @@ int esmk_debug_linear_splitk(const void* a_dev, const void* w_dev, float* partia
 int esmk_debug_gemm_timing(void* stamps_dev);
 
 /* Measurement / A-B hook (no reference counterpart): which persistent GEMM kernel serves the dense nn.Linear calls
- * from now on — 8 = gemm8.hip (two waves per SIMD, default), 9 = gemm9.hip (one wave per SIMD, 128 x 128 wave
- * blocks; bit-identical results).  `variant` selects a gemm9 DMA schedule / timing experiment (gemm9.hip).
- * The environment variable ESMK_GEMM_IMPL=9[:variant] sets the same thing for a whole process. */
+ * from now on — 8 = gemm8.hip (two waves per SIMD), 9 = gemm9.hip (one wave per SIMD, 128 x 128 wave blocks;
+ * bit-identical results) wherever it applies, 0 = the library's own choice per call (default).  `variant` selects a
+ * gemm9 barrier placement / timing experiment (gemm9.hip).  The environment variable ESMK_GEMM_IMPL=8|9[:variant]|auto
+ * sets the same thing for a whole process. */
 int esmk_debug_gemm_impl(int impl, int variant);
 
 /* Fused q/k/v projection + scaling + rotary + head split (multihead_attention.py:256-284,
