@@ -34,6 +34,7 @@ class EsmkConfig(ctypes.Structure):
         ("no_rope", c_int32),
         ("num_positions", c_int32),
         ("ln_before", c_int32),
+        ("weight_split", c_int32),
     ]
 
 
@@ -101,6 +102,8 @@ SIGNATURES = {
     ),
     "esmk_debug_gemm_timing": (c_int, [c_void_p]),
     "esmk_debug_gemm_impl": (c_int, [c_int, c_int]),
+    "esmk_op_split_weight": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "esmk_op_linear_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "esmk_debug_linear_splitk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "esmk_op_qkv_rope": (
         c_int,

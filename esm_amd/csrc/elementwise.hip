@@ -516,6 +516,41 @@ static hipError_t convert2d_from(const S* src, void* dst, int dst_dtype, size_t 
     return hipGetLastError();
 }
 
+template <typename S>
+__global__ __launch_bounds__(256) void convert2d_split_kernel(const S* __restrict__ src, _Float16* __restrict__ dst,
+                                                               size_t rows, size_t cols, size_t dst_ld, int row_map,
+                                                               int col_map, int d) {
+    const size_t n = rows * cols;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        const size_t r = i / cols, c = i - r * cols;
+        const size_t rr = row_map ? head_pad_index(r, d) : r;
+        const size_t cc = col_map ? head_pad_index(c, d) : c;
+        const float w = (float)src[i];
+        const _Float16 hi = (_Float16)w;
+        const _Float16 lo = (_Float16)(w - (float)hi);
+        _Float16* q = dst + rr * 2 * dst_ld + (cc >> 6) * 128 + (cc & 63);
+        q[0] = hi;
+        q[64] = lo;
+    }
+}
+
+hipError_t launch_convert2d_split(const void* src, int src_dtype, void* dst, size_t rows, size_t cols, size_t dst_ld,
+                                  int row_map, int col_map, int d, hipStream_t st) {
+    if (rows * cols == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((rows * cols + 255) / 256, 4096);
+#define ESMK_C2S(ST) \
+    hipLaunchKernelGGL((convert2d_split_kernel<ST>), dim3(blocks), dim3(256), 0, st, (const ST*)src, (_Float16*)dst, rows, \
+                       cols, dst_ld, row_map, col_map, d)
+    if (src_dtype == ESMK_DT_F32) ESMK_C2S(float);
+    else if (src_dtype == ESMK_DT_F16) ESMK_C2S(_Float16);
+    else if (src_dtype == ESMK_DT_BF16) ESMK_C2S(__bf16);
+    else return hipErrorInvalidValue;
+#undef ESMK_C2S
+    return hipGetLastError();
+}
+
 hipError_t launch_convert2d(const void* src, int src_dtype, void* dst, int dst_dtype, size_t rows, size_t cols,
                             size_t dst_ld, int row_map, int col_map, int d, hipStream_t st) {
     if (rows * cols == 0) return hipSuccess;

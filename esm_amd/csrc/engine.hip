@@ -37,12 +37,14 @@ namespace {
 void plan_packed(esmk_model* m) {
     const size_t os = op_size(m->cfg.operand_dtype);
     const size_t E = m->E, F = m->F, V = m->V, EA = m->EA, Kp = m->Kp;
+    const size_t ws = m->cfg.weight_split ? 2 : 1;  // f16x2: every layer matrix as [rows, 2 cols] (hi | lo K tiles)
     Carve c;
     m->embed_f32 = c.take(V * E * 4);
     m->embed_op = c.take(V * Kp * os);
     m->fin_g = c.take(E * 4);
     m->fin_b = c.take(E * 4);
     m->lm_w = c.take(E * Kp * os);
+    m->lm_w32 = c.take(ws == 2 ? E * E * 4 : 0);
     m->lm_b = c.take(E * 4);
     m->lm_lng = c.take(E * 4);
     m->lm_lnb = c.take(E * 4);
@@ -57,13 +59,13 @@ void plan_packed(esmk_model* m) {
     m->layer.resize(m->L);
     for (int l = 0; l < m->L; ++l) {
         LayerOff& o = m->layer[l];
-        o.wqkv = c.take(3 * EA * Kp * os);
+        o.wqkv = c.take(3 * EA * Kp * os * ws);
         o.bqkv = c.take(3 * EA * 4);
-        o.wo = c.take(E * EA * os);
+        o.wo = c.take(E * EA * os * ws);
         o.bo = c.take(E * 4);
-        o.w1 = c.take(F * Kp * os);
+        o.w1 = c.take(F * Kp * os * ws);
         o.b1 = c.take(F * 4);
-        o.w2 = c.take(E * F * os);
+        o.w2 = c.take(E * F * os * ws);
         o.b2 = c.take(E * 4);
         o.ln1g = c.take(E * 4);
         o.ln1b = c.take(E * 4);
@@ -225,6 +227,8 @@ int esmk_create(const esmk_config* cfg, esmk_model** out) {
                     "heads are spread over 64 slots at pack time)");
     if (cfg->embed_dim % 8 != 0 || cfg->ffn_dim % 64 != 0)
         return fail("esmk_create: embed_dim must be a multiple of 8 and ffn_dim a multiple of 64");
+    if (cfg->weight_split != 0 && cfg->operand_dtype != ESMK_F16)
+        return fail("esmk_create: weight_split (precision mode f16x2) needs operand_dtype ESMK_F16");
     esmk_model* m = new esmk_model();
     m->cfg = *cfg;
     m->L = cfg->num_layers;
@@ -307,6 +311,16 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
         ESMK_TRY(launch_convert2d(src_dev, src_dtype, base + off, dst_dtype, rows, cols, ld, rmap, cmap, hd, st));
         return 0;
     };
+    // a matrix of the layer stack: plain operand-dtype image, or (f16x2) the hi | lo split image with rows of 2 ld
+    const size_t ws = m->cfg.weight_split ? 2 : 1;
+    auto putw = [&](size_t off, size_t rows, size_t cols, size_t ld, int rmap, int cmap) -> int {
+        if (ws == 1) return put2d(off, op, rows, cols, ld, rmap, cmap);
+        if (n != rows * cols)
+            return fail(std::string("esmk_pack_weight: ") + key + " has " + std::to_string(n) +
+                        " elements, expected " + std::to_string(rows * cols));
+        ESMK_TRY(launch_convert2d_split(src_dev, src_dtype, base + off, rows, cols, ld, rmap, cmap, hd, st));
+        return 0;
+    };
     if (!strcmp(key, "embed_tokens.weight")) {
         if (put(m->embed_f32, ESMK_DT_F32, V * E)) return 1;
         return put2d(m->embed_op, op, V, E, Kp, 0, 0);
@@ -355,7 +369,10 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
     if (!m->is_msa && m->cfg.ln_before && !strcmp(key, "emb_layer_norm_before.bias")) return put(m->lnb_b, ESMK_DT_F32, E);
     if (!strcmp(key, "emb_layer_norm_after.weight")) return put(m->fin_g, ESMK_DT_F32, E);
     if (!strcmp(key, "emb_layer_norm_after.bias")) return put(m->fin_b, ESMK_DT_F32, E);
-    if (!strcmp(key, "lm_head.dense.weight")) return put2d(m->lm_w, op, E, E, Kp, 0, 0);
+    if (!strcmp(key, "lm_head.dense.weight")) {
+        if (m->cfg.weight_split && put(m->lm_w32, ESMK_DT_F32, E * E)) return 1;
+        return put2d(m->lm_w, op, E, E, Kp, 0, 0);
+    }
     if (!strcmp(key, "lm_head.dense.bias")) return put(m->lm_b, ESMK_DT_F32, E);
     if (!strcmp(key, "lm_head.layer_norm.weight")) return put(m->lm_lng, ESMK_DT_F32, E);
     if (!strcmp(key, "lm_head.layer_norm.bias")) return put(m->lm_lnb, ESMK_DT_F32, E);
@@ -371,18 +388,18 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
         const char* sub = end + 1;
         const LayerOff& o = m->layer[l];
         // q/k/v: output rows are head dims -> spread over 64 slots; input columns padded to Kp
-        if (!strcmp(sub, "self_attn.q_proj.weight")) return put2d(o.wqkv, op, E, E, Kp, qkmap, 0);
-        if (!strcmp(sub, "self_attn.k_proj.weight")) return put2d(o.wqkv + EA * Kp * os, op, E, E, Kp, qkmap, 0);
-        if (!strcmp(sub, "self_attn.v_proj.weight")) return put2d(o.wqkv + 2 * EA * Kp * os, op, E, E, Kp, padmap, 0);
+        if (!strcmp(sub, "self_attn.q_proj.weight")) return putw(o.wqkv, E, E, Kp, qkmap, 0);
+        if (!strcmp(sub, "self_attn.k_proj.weight")) return putw(o.wqkv + EA * Kp * os * ws, E, E, Kp, qkmap, 0);
+        if (!strcmp(sub, "self_attn.v_proj.weight")) return putw(o.wqkv + 2 * EA * Kp * os * ws, E, E, Kp, padmap, 0);
         if (!strcmp(sub, "self_attn.q_proj.bias")) return put2d(o.bqkv, ESMK_DT_F32, 1, E, EA, 0, qkmap);
         if (!strcmp(sub, "self_attn.k_proj.bias")) return put2d(o.bqkv + EA * 4, ESMK_DT_F32, 1, E, EA, 0, qkmap);
         if (!strcmp(sub, "self_attn.v_proj.bias")) return put2d(o.bqkv + 2 * EA * 4, ESMK_DT_F32, 1, E, EA, 0, padmap);
         // out_proj consumes the attention context: its input columns follow the same slot layout
-        if (!strcmp(sub, "self_attn.out_proj.weight")) return put2d(o.wo, op, E, E, EA, 0, padmap);
+        if (!strcmp(sub, "self_attn.out_proj.weight")) return putw(o.wo, E, E, EA, 0, padmap);
         if (!strcmp(sub, "self_attn.out_proj.bias")) return put(o.bo, ESMK_DT_F32, E);
-        if (!strcmp(sub, "fc1.weight")) return put2d(o.w1, op, F, E, Kp, 0, 0);
+        if (!strcmp(sub, "fc1.weight")) return putw(o.w1, F, E, Kp, 0, 0);
         if (!strcmp(sub, "fc1.bias")) return put(o.b1, ESMK_DT_F32, F);
-        if (!strcmp(sub, "fc2.weight")) return put(o.w2, op, E * F);
+        if (!strcmp(sub, "fc2.weight")) return putw(o.w2, E, F, F, 0, 0);
         if (!strcmp(sub, "fc2.bias")) return put(o.b2, ESMK_DT_F32, E);
         if (!strcmp(sub, "self_attn_layer_norm.weight")) return put(o.ln1g, ESMK_DT_F32, E);
         if (!strcmp(sub, "self_attn_layer_norm.bias")) return put(o.ln1b, ESMK_DT_F32, E);
@@ -589,6 +606,20 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         ESMK_TRY(launch_gemm(a, epi, op, st));
         return 0;
     };
+    // a GEMM of the layer stack: with split weights (f16x2) the same kernel runs over the [N, 2K] hi | lo image, the
+    // activations' K tile kt / 2 meeting W_hi (kt even) and W_lo (kt odd); FLOP / byte accounting stays algorithmic
+    const int wsf = m->cfg.weight_split ? 2 : 1;
+    auto layer_gemm = [&](int cls, GemmArgs a, int epi, double out_bytes_per_elem) -> int {
+        if (wsf == 1) return gemm(cls, a, epi, out_bytes_per_elem);
+        const double fl = 2.0 * a.M * (double)a.N * a.K;
+        const double by = ((double)a.M * a.K + 2.0 * a.N * a.K) * os + (double)a.M * a.N * out_bytes_per_elem;
+        a.a_row_bytes = (long long)a.K * (long long)os;
+        a.a_kt_repeat = 1;
+        a.K *= 2;
+        ProfScope ps(m, st, cls, fl, by);
+        ESMK_TRY(launch_gemm(a, epi, op, st));
+        return 0;
+    };
     auto lnorm = [&](const float* in, size_t go, size_t bo, void* y, float* y32) -> int {
         ProfScope ps(m, st, PC_LAYERNORM, 8 * NE, NE * (4 + (y ? os : 0) + (y32 ? 4 : 0)));
         LnExtra ex;
@@ -643,7 +674,7 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         const char* e = getenv("ESMK_QKV_FORK");
         return e != nullptr && atoi(e) != 0;
     }();
-    const bool fork_v = env_fork && !m->prof_on;
+    const bool fork_v = env_fork && !m->prof_on && !m->cfg.weight_split;
     if (fork_v && !m->side_stream) {
         ESMK_TRY(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
         ESMK_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
@@ -681,7 +712,7 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         g.row_pos = row_pos;
         GemmArgs gv = g;
         gv.row_pos = nullptr;
-        gv.W = pk + o.wqkv + (size_t)2 * EA * Kp * os;           // v: weight rows [2EA,3EA)
+        gv.W = pk + o.wqkv + (size_t)2 * EA * Kp * os * wsf;     // v: weight rows [2EA,3EA)
         gv.bias = (const float*)(pk + o.bqkv) + 2 * EA;
         gv.N = EA;
         if (fork_v) {
@@ -694,8 +725,8 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
             if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;  // q, k: weight rows [0,2EA)
             ESMK_TRY(hipStreamWaitEvent(st, m->ev_join, 0));
         } else {
-            if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;  // q, k: weight rows [0,2EA)
-            if (gemm(PC_GEMM_QKV, gv, EPI_V_T, os)) return 1;
+            if (layer_gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;  // q, k: weight rows [0,2EA)
+            if (layer_gemm(PC_GEMM_QKV, gv, EPI_V_T, os)) return 1;
         }
         {
             // 4 T d flop per (query, head) pair: QK^T and PV; q,k,v read + ctx written
@@ -736,7 +767,7 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         g.M = N;
         g.N = E;
         g.K = EA;
-        if (gemm(PC_GEMM_OUT, g, EPI_RESID_F32, 8)) return 1;
+        if (layer_gemm(PC_GEMM_OUT, g, EPI_RESID_F32, 8)) return 1;
         if (lnorm(x, o.ln2g, o.ln2b, h, nullptr)) return 1;
         g = GemmArgs();
         g.A = h;
@@ -746,7 +777,7 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         g.M = N;
         g.N = F;
         g.K = Kp;
-        if (gemm(PC_GEMM_FC1, g, EPI_GELU_T, os)) return 1;
+        if (layer_gemm(PC_GEMM_FC1, g, EPI_GELU_T, os)) return 1;
         g = GemmArgs();
         g.A = ffn;
         g.W = pk + o.w2;
@@ -755,7 +786,7 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         g.M = N;
         g.N = E;
         g.K = F;
-        if (gemm(PC_GEMM_FC2, g, EPI_RESID_F32, 8)) return 1;
+        if (layer_gemm(PC_GEMM_FC2, g, EPI_RESID_F32, 8)) return 1;
         if (l + 1 < L && repr_copy(l + 1, x)) return 1;  // esm2.py:117-118
     }
 
@@ -785,7 +816,23 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
             if (repr_layers[i] == L && repr_out_dev[i] != rep_last)
                 ESMK_TRY(launch_copy_f32(rep_last, (float*)repr_out_dev[i], (size_t)N * E, st));
     }
-    if (want_logits) {  // modules.py:308-314
+    if (want_logits && m->cfg.weight_split && E % 32 == 0) {
+        // f16x2 precision mode: the head (modules.py:308-314) in fp32 on the exact-fp32 MFMA path — two small GEMMs per
+        // forward; neither its weights nor its activations are rounded to fp16, so the logits carry only the error of
+        // the representation itself
+        float* a32 = (!repr_lowp && rep_last != nullptr) ? rep_last : g32;
+        if (a32 == g32 && lnorm(x, m->fin_g, m->fin_b, nullptr, g32)) return 1;  // the normalised stream in fp32
+        {
+            ProfScope ps(m, st, PC_LM_DENSE, 2.0 * N * (double)E * E, (2.0 * NE + (double)E * E) * 4);
+            ESMK_TRY(launch_gemm32(a32, E, (const float*)(pk + m->lm_w32), (const float*)(pk + m->lm_b), x, E, N, E, E, true, st));
+        }
+        if (lnorm(x, m->lm_lng, m->lm_lnb, nullptr, g32)) return 1;  // x (the residual stream) is dead: dense output
+        {
+            ProfScope ps(m, st, PC_LM_LOGITS, 2.0 * N * (double)E * m->V, (NE + (double)m->V * E + (double)N * m->V) * 4);
+            ESMK_TRY(launch_gemm32(g32, E, (const float*)(pk + m->embed_f32), (const float*)(pk + m->lm_bias),
+                                   (float*)logits_out_dev, m->V, N, m->V, E, false, st));
+        }
+    } else if (want_logits) {  // modules.py:308-314
         g = GemmArgs();
         g.A = h;
         g.W = pk + m->lm_w;
@@ -903,6 +950,31 @@ int esmk_op_linear(const void* a_dev, const void* w_dev, const float* bias_dev, 
     g.dbg = (operand_dtype >> 12) & 0xff;             // timing experiments (tools/microbench.py)
     operand_dtype &= 0xff;
     ESMK_TRY(launch_gemm(g, epilogue, operand_dtype, (hipStream_t)stream));
+    return 0;
+}
+
+int esmk_op_split_weight(const void* w_dev, int w_dtype, void* w2_dev, int N, int K, void* stream) {
+    if (!w_dev || !w2_dev) return fail("esmk_op_split_weight: null argument");
+    if (N <= 0 || K <= 0 || K % 64 != 0) return fail("esmk_op_split_weight: need N > 0 and K a positive multiple of 64");
+    ESMK_TRY(launch_convert2d_split(w_dev, w_dtype, w2_dev, (size_t)N, (size_t)K, (size_t)K, 0, 0, 64, (hipStream_t)stream));
+    return 0;
+}
+
+int esmk_op_linear_split(const void* a_dev, const void* w2_dev, const float* bias_dev, void* out_dev, int M, int N, int K,
+                         int epilogue, void* stream) {
+    if (epilogue < 0 || epilogue > 4 || epilogue == EPI_GELU_F32) return fail("esmk_op_linear_split: epilogue must be 0, 1, 2 or 4");
+    if (K % 64 != 0 || N % 8 != 0) return fail("esmk_op_linear_split: need K % 64 == 0 and N % 8 == 0");
+    GemmArgs g;
+    g.A = a_dev;
+    g.W = w2_dev;
+    g.bias = bias_dev;
+    g.out = out_dev;
+    g.M = M;
+    g.N = N;
+    g.K = 2 * K;
+    g.a_row_bytes = (long long)K * 2;
+    g.a_kt_repeat = 1;
+    ESMK_TRY(launch_gemm(g, epilogue, ESMK_DT_F16, (hipStream_t)stream));
     return 0;
 }
 

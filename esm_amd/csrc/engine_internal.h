@@ -58,6 +58,7 @@ struct esmk_model {
     int Kp = 0;  // E rounded up to the 64-wide K tile: row stride of the normalised activations
     // packed parameter image layout (byte offsets)
     size_t embed_f32, embed_op, fin_g, fin_b, lm_w, lm_b, lm_lng, lm_lnb, lm_bias, ct_w, ct_b;
+    size_t lm_w32 = 0;  // f16x2 precision mode: lm_head.dense.weight in fp32 (the head runs on the fp32 MFMA path)
     std::vector<esmk_host::LayerOff> layer;
     size_t packed_bytes;
     // RoPE

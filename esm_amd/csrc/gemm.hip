@@ -562,11 +562,12 @@ static hipError_t dispatch(const GemmArgs& p, int epi, hipStream_t st) {
 }
 
 // Which persistent kernel serves a dense call.  g_impl: 8 = gemm8 always, 9 = gemm9 wherever it applies, 0 = auto:
-// gemm9 for the calls it measurably wins (profiles/r3_gemm9_schedC_variants.log: the long-K residual GEMM, fc2:
-// +6 %; the K = 1280 shapes lose their gain in the epilogue / seam), gemm8 otherwise.  Both give the same bits.
-// ESMK_GEMM_IMPL = 8 | 9 | 9:<variant> | auto;  ESMK_GEMM9_MASK = bit mask over epilogue codes for auto (default
-// 1 << EPI_RESID_F32), ESMK_GEMM9_MIN_K (default 2560).
-static int g_impl = -1, g_impl_var = 0, g_mask9 = 1 << EPI_RESID_F32, g_mink9 = 2560;
+// gemm9 for the calls it measurably wins in the forward (profiles/r3_gemm9_forward_ab.log, one box: the q/k and v
+// projections 22.65 -> 20.95 ms per step, the long-K residual GEMM fc2 25.7 -> 25.0; fc1 + GELU and the out projection
+// are gemm8's: their gain in the loop is lost in the single-wave epilogue), gemm8 otherwise.  Both give the same bits.
+// ESMK_GEMM_IMPL = 8 | 9 | 9:<variant> | auto;  ESMK_GEMM9_MASK = bit mask over epilogue codes for auto,
+// ESMK_GEMM9_MIN_K = shortest K of the residual GEMM that goes to gemm9 (default 2560).
+static int g_impl = -1, g_impl_var = 0, g_mask9 = (1 << EPI_RESID_F32) | (1 << EPI_QKV_ROPE) | (1 << EPI_V_T), g_mink9 = 2560;
 void gemm_set_impl(int impl, int var) {
     g_impl = impl;
     g_impl_var = var;
@@ -589,7 +590,8 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
         if (g_impl == 9) return launch_gemm9(p, epi, operand_dtype, g_impl_var, st);
         // auto: only launches that fill the chip for at least one round (small batches keep gemm8's half-height tiles)
         const long long tiles = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-        if (((g_mask9 >> epi) & 1) && p.K >= g_mink9 && tiles >= 256) return launch_gemm9(p, epi, operand_dtype, 0, st);
+        if (((g_mask9 >> epi) & 1) && (epi != EPI_RESID_F32 || p.K >= g_mink9) && tiles >= 256)
+            return launch_gemm9(p, epi, operand_dtype, 0, st);
     }
     if (!env_old && !p.force_old && !p.force_generic && gemm8_supports(p, epi))
         return launch_gemm8(p, epi, operand_dtype, st);

@@ -150,7 +150,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
         // K tile is re-issued (into a dead buffer) so the vmcnt bookkeeping stays uniform
         if (s.kt + 1 < nk) {
             s.kt = __builtin_amdgcn_readfirstlane(s.kt + 1);
-            if constexpr (!(DBG & 64)) s.base += (unit == 0 || unit == 3) ? a_kt : w_kt;
+            if constexpr (!(DBG & 64)) {
+                if (unit == 0 || unit == 3) {
+                    // split weights: the activations' K tile kt / 2 meets W_hi (kt even) and W_lo (kt odd)
+                    if (!(GEN && p.a_kt_repeat) || !(s.kt & 1)) s.base += a_kt;
+                } else {
+                    s.base += w_kt;
+                }
+            }
         } else if (s.it + 1 < n_my) {
             set_tile(s, unit, s.it + 1);
         }
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
 // --------------------------------------------------------------------------------------------
 // generalised addressing requested?  (MSA Transformer calls, batched / strided / remapped GEMMs, packed batches)
 bool gemm8_generalised(const GemmArgs& p, int epi) {
-    return p.a_row_bytes || p.w_row_bytes || p.a_kt_bytes || p.w_kt_bytes || p.batch > 1 || p.n_valid > 0 ||
+    return p.a_row_bytes || p.w_row_bytes || p.a_kt_bytes || p.w_kt_bytes || p.a_kt_repeat || p.batch > 1 || p.n_valid > 0 ||
            p.ldc > 0 || p.row_keep != nullptr || p.vt_rows > 0 || p.rowmap_R > 0 || epi == EPI_MSA_CTX ||
            p.head_dim != 64 || p.row_pos != nullptr;
 }

@@ -174,10 +174,12 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x16 (&acc)[2][2][4], int m_base,
                         const f32x4 s = *reinterpret_cast<const f32x4*>(p.sin + (size_t)tt * 32 + 8 * g4 + 4 * e2);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
+                            // the contraction hipcc chose for epilogue8's `a1*c - a2*s`, `a2*c + a1*s`, spelled out:
+                            // bit-identical q / k whichever kernel ran (packed == padded == alone stays exact)
                             const float x1 = a1[4 * e2 + e] * sc;
                             const float x2 = a2[4 * e2 + e] * sc;
-                            y1[4 * e2 + e] = x1 * c[e] - x2 * s[e];
-                            y2[4 * e2 + e] = x2 * c[e] + x1 * s[e];
+                            y1[4 * e2 + e] = __builtin_fmaf(x1, c[e], -(x2 * s[e]));
+                            y2[4 * e2 + e] = __builtin_fmaf(x2, c[e], x1 * s[e]);
                         }
                     }
                     V8 o1, o2;

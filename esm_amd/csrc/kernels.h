@@ -41,6 +41,9 @@ struct GemmArgs {
     // ---- generalised addressing of the persistent kernel (gemm8.hip); 0 = dense default ------------
     long long a_row_bytes = 0, w_row_bytes = 0;  // stride between consecutive operand rows (2K)
     long long a_kt_bytes = 0, w_kt_bytes = 0;    // stride between consecutive 64-wide K tiles (128)
+    int a_kt_repeat = 0;                         // 1: the A stream stays on each K tile for TWO stream positions (split
+                                                 // weights, W = W_hi + W_lo stored as interleaved K tiles [hi0 lo0 hi1 ...]:
+                                                 // K counts the 2 K_real columns of that image, a_row_bytes = 2 K_real)
     int batch = 1, batch_inner = 1;              // batched GEMM: z = zo * batch_inner + zi
     long long a_bo = 0, a_bi = 0, w_bo = 0, w_bi = 0, o_bo = 0, o_bi = 0;  // byte offsets per zo / zi
     int n_valid = 0;                  // W rows that exist (default N): loads of rows >= n_valid are clamped
@@ -59,6 +62,10 @@ bool gemm8_supports(const GemmArgs& p, int epi);
 bool gemm8_generalised(const GemmArgs& p, int epi);  // uses fields only the persistent kernel implements
 bool gemm8_half_height(const GemmArgs& p);            // dense kernels: 128 x 256 tiles for this shape?
 hipError_t launch_gemm8(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st);
+// gemm32.hip: fp32 in / fp32 accumulate / fp32 out on the exact-fp32 MFMA path (1/16 of the fp16 rate): the LM head of
+// the f16x2 precision mode.  A [M,K] row stride lda, W [N,K], out [M,N] row stride ldc; K % 32 == 0, lda % 4 == 0
+hipError_t launch_gemm32(const float* A, int lda, const float* W, const float* bias, float* out, int ldc, int M, int N,
+                         int K, bool gelu, hipStream_t st);
 // measurement hook: per-tile s_memtime stamps of workgroup-leader lanes ([workgroup][tile & 31][4])
 void gemm8_set_timing(unsigned long long* dev_buf);
 // gemm9.hip: the same contract on one wave per SIMD (128 x 128 wave blocks); dense operands only.  var selects the
@@ -112,6 +119,11 @@ hipError_t launch_convert(const void* src, int src_dtype, void* dst, int dst_dty
 // [rows, cols] -> dst with row stride dst_ld; row_map / col_map = 1 spreads head_dim-d heads over 64 slots
 hipError_t launch_convert2d(const void* src, int src_dtype, void* dst, int dst_dtype, size_t rows, size_t cols,
                             size_t dst_ld, int row_map, int col_map, int d, hipStream_t st);
+// split-weight image (operand mode f16x2): src [rows, cols] -> dst fp16 [rows, 2 dst_ld]; 64-column K tile t of row r
+// becomes hi = fp16(w) at dst[r][128 t .. +63] and lo = fp16(w - hi) at dst[r][128 t + 64 .. +127]
+// (hi + lo carries ~19-22 bits of w: the MFMA takes fp16 subnormals as they are); row_map / col_map as above
+hipError_t launch_convert2d_split(const void* src, int src_dtype, void* dst, size_t rows, size_t cols, size_t dst_ld,
+                                  int row_map, int col_map, int d, hipStream_t st);
 // RoPE tables cos/sin[t][i] = cos/sin(t * inv_freq[i]) (rotary_embedding.py:47-61), fp32
 hipError_t launch_rope_table(const float* inv_freq, float* cos, float* sin, int T, int half,
                              hipStream_t st);

@@ -91,11 +91,18 @@ def _native_lowp(param_dtype, operand_dtype):
     return param_dtype in (torch.float16, torch.bfloat16) and param_dtype == operand_dtype
 
 
+def _weight_split():
+    """``ESM_AMD_OPERAND=f16x2``: precision mode with split weights (W = W_hi + W_lo, both fp16, two MFMA passes per
+    layer GEMM): removes the weight rounding — two thirds of the fp16-operand error of a deep stack — at 2x the GEMM
+    time.  ESM-2 / ESM-1b engines only (the MSA Transformer ignores it and runs plain fp16)."""
+    return os.environ.get("ESM_AMD_OPERAND", "").lower() in ("f16x2", "fp16x2")
+
+
 def _operand_dtype_for(param_dtype):
     env = os.environ.get("ESM_AMD_OPERAND", "").lower()
     if env in ("bf16", "bfloat16"):
         return torch.bfloat16
-    if env in ("f16", "fp16", "float16", "half"):
+    if env in ("f16", "fp16", "float16", "half", "f16x2", "fp16x2"):
         return torch.float16
     # fp16 operands keep the 33-layer stack within 1e-3 of the fp32 reference (bf16: ~5e-3)
     return torch.bfloat16 if param_dtype == torch.bfloat16 else torch.float16
@@ -148,12 +155,13 @@ def warn_if_grad_expected(model):
 class _Engine:
     """One esmk_model handle + packed parameter image + workspace for one (device, dtype)."""
 
-    def __init__(self, model: "ESM2", device, operand_dtype):
+    def __init__(self, model: "ESM2", device, operand_dtype, weight_split=False):
         from . import _native as N
 
         self.N = N
         self.device = device
         self.operand_dtype = operand_dtype
+        self.weight_split = bool(weight_split)
         # ESM-1b / ESM-1v (esm_amd.esm1.ProteinBertModel) set these; ESM-2 leaves them at zero
         self.no_rope = int(getattr(model, "_engine_no_rope", 0))
         num_positions = int(getattr(model, "_engine_num_positions", 0))
@@ -162,7 +170,7 @@ class _Engine:
             model.num_layers, model.embed_dim, model.attention_heads, int(getattr(model, "ffn_embed_dim", 4 * model.embed_dim)),
             model.alphabet_size, model.padding_idx, model.mask_idx, model.cls_idx, model.eos_idx,
             int(bool(model.token_dropout)), int(bool(model.prepend_bos)), int(bool(model.append_eos)),
-            N.dtype_code(operand_dtype), self.no_rope, num_positions, ln_before,
+            N.dtype_code(operand_dtype), self.no_rope, num_positions, ln_before, int(self.weight_split),
         )
         self.handle = ctypes.c_void_p()
         with torch.cuda.device(device):
@@ -275,11 +283,12 @@ class ESM2(nn.Module):
     def _get_engine(self, device):
         pdt = self.embed_tokens.weight.dtype
         odt = _operand_dtype_for(pdt)
+        split = _weight_split()
         eng = self._engine
-        if eng is None or eng.device != device or eng.operand_dtype != odt:
+        if eng is None or eng.device != device or eng.operand_dtype != odt or eng.weight_split != split:
             if eng is not None:
                 eng.close()
-            eng = _Engine(self, device, odt)
+            eng = _Engine(self, device, odt, split)
             object.__setattr__(self, "_engine", eng)
         return eng
 

@@ -105,34 +105,54 @@ class _Writer:
     """Background result writer: the device->host copy of batch i (on its own HIP stream, into pinned
     buffers) and the slicing / ``torch.save`` of its sequences overlap the forward pass of batch i+1
     (SURVEY.md §8 d: 335 MB of fp32 per 64 x 1022 batch would otherwise serialise behind the compute).
-    At most ``depth`` batches are in flight, which bounds the pinned memory."""
+    A batch is submitted as several CHUNK jobs (a few sequences each), so that all ``threads`` work on it at once
+    (``torch.save`` releases the GIL for most of its time); at most ``depth`` batches are in flight, which bounds
+    the pinned memory; ``done`` runs once after a batch's last chunk."""
 
     def __init__(self, depth=3, threads=2):
         self.q = queue.Queue()
         self.slots = threading.Semaphore(depth)
         self.errors: List[BaseException] = []
+        self.lock = threading.Lock()
         self.threads = [threading.Thread(target=self._run, daemon=True) for _ in range(threads)]
         for t in self.threads:
             t.start()
 
     def _run(self):
         while True:
-            job = self.q.get()
-            if job is None:
+            item = self.q.get()
+            if item is None:
                 return
+            job, state = item
             try:
                 job()
             except BaseException as e:  # surfaced by close()
                 self.errors.append(e)
             finally:
-                self.slots.release()
+                with self.lock:
+                    state["left"] -= 1
+                    last = state["left"] == 0
+                if last:
+                    try:
+                        if state["done"] is not None:
+                            state["done"]()
+                    except BaseException as e:
+                        self.errors.append(e)
+                    finally:
+                        self.slots.release()
 
-    def submit(self, job):
+    def submit(self, jobs, done=None):
+        """``jobs``: the chunk jobs of ONE batch (a single callable is one chunk)."""
+        jobs = [jobs] if callable(jobs) else list(jobs)
         self.slots.acquire()
-        if self.errors:
+        if self.errors or not jobs:
             self.slots.release()
-            raise self.errors[0]
-        self.q.put(job)
+            if self.errors:
+                raise self.errors[0]
+            return
+        state = {"left": len(jobs), "done": done}
+        for job in jobs:
+            self.q.put((job, state))
 
     def close(self):
         for _ in self.threads:
@@ -168,11 +188,13 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
             output_dir: Optional[pathlib.Path] = None, toks_per_batch: int = 4096,
             truncation_seq_length: int = 1022, device: Optional[torch.device] = None,
             gather_mean: bool = True, log: Callable[[str], None] = print, writer_threads: int = 0,
-            writer_depth: int = 4):
+            writer_depth: int = 4, async_host: bool = False, chunk_rows: int = 8):
     """Run the sharded extraction.  ``embed_fn(tokens, repr_layers, return_contacts)`` is the model
     forward (``ESM2.__call__`` / ``ESM2.forward_varlen`` in production; an ``embed_fn.wants_lengths = True``
     attribute asks for the extra keyword ``lengths`` = per-row token counts, taken from the host copy).  Returns ``{layer: [n_sequences, E] mean embeddings}``
-    in dataset order when ``gather_mean`` (every rank gets the full matrix), else ``{}``."""
+    in dataset order when ``gather_mean`` (every rank gets the full matrix), else ``{}``.
+    ``async_host``: run the writer-thread pipeline also without a GPU (host-side scaling tests: 8 ranks x (tokeniser +
+    writers) on one host, tests/test_extract_sharded.py); ``chunk_rows``: sequences per writer job."""
     dist, rank, world = _dist_info()
     assert all(-(num_layers + 1) <= i <= num_layers for i in repr_layers)
     # duplicates (e.g. --repr_layers -1 33) collapse, first occurrence wins: the reference builds dicts keyed by layer
@@ -205,8 +227,8 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
         return {l: torch.stack([t[i, 1:int(k) + 1].float().mean(0) for i, k in enumerate(n)]).to(t.dtype)
                 for l, t in reps.items()}
 
-    def finish(ids, labels, strs, reps, contacts, means_b):
-        """Per-sequence results of one batch from HOST tensors (reference scripts/extract.py:104-131)."""
+    def finish(ids, labels, strs, reps, contacts, means_b, rows=None):
+        """Per-sequence results of (rows ``rows`` of) one batch from HOST tensors (reference scripts/extract.py:104-131)."""
         rows_idx, rows_mean = [], {l: [] for l in layers}
         # torch.save of a VIEW writes the view's whole storage (the batch).  A slice [row, a:b] of the contiguous
         # host tensor is itself one contiguous run of memory: re-wrapping it (numpy view -> from_numpy; bf16 goes
@@ -217,7 +239,8 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
             if t.dtype == torch.bfloat16:
                 return torch.from_numpy(t.view(torch.int16).numpy()).view(torch.bfloat16)
             return torch.from_numpy(t.numpy())
-        for row, (seq_id, label) in enumerate(zip(ids, labels)):
+        for row in (range(len(ids)) if rows is None else rows):
+            seq_id, label = ids[row], labels[row]
             n = min(truncation_seq_length, len(strs[row]))
             result = {"label": label}
             if "per_tok" in include:
@@ -242,7 +265,9 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
                 my_means[l].extend(rows_mean[l])
 
     on_gpu = device is not None and device.type == "cuda"
-    writer = _Writer(depth=writer_depth, threads=writer_threads or default_writer_threads()) if on_gpu else None
+    use_writer = on_gpu or async_host
+    n_threads = writer_threads or default_writer_threads()
+    writer = _Writer(depth=writer_depth, threads=n_threads) if use_writer else None
     pool = _PinnedPool() if on_gpu else None
     copy_stream = torch.cuda.Stream(device) if on_gpu else None
     with torch.no_grad():
@@ -259,40 +284,52 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
             reps = {l: t for l, t in out["representations"].items()}
             contacts = out["contacts"] if return_contacts else None
             means_dev = batch_means(reps, strs)
-            if not on_gpu:
+            if not use_writer:
                 finish(ids, labels, strs, {l: t.to("cpu") for l, t in reps.items()},
                        contacts.to("cpu") if contacts is not None else None, {l: m.to("cpu") for l, m in means_dev.items()})
                 continue
             need_full = ("per_tok" in include) or ("bos" in include)
-            # device -> pinned host on the copy stream, results handled by the writer threads
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(device))
-            host_reps, host_contacts, host_means = {}, None, {}
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(ready)
-                for l, t in reps.items():
-                    if not need_full:  # only the [B,E] means leave the device
-                        t = t[:, :1, :]
-                    host_reps[l] = pool.take(t)
-                    host_reps[l].copy_(t, non_blocking=True)
-                    host_means[l] = pool.take(means_dev[l])
-                    host_means[l].copy_(means_dev[l], non_blocking=True)
-                if contacts is not None:
-                    host_contacts = pool.take(contacts)
-                    host_contacts.copy_(contacts, non_blocking=True)
-                copied = torch.cuda.Event()
-                copied.record(copy_stream)
+            host_reps, host_contacts, host_means, copied = {}, None, {}, None
+            if on_gpu:
+                # device -> pinned host on the copy stream, results handled by the writer threads
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(device))
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(ready)
+                    for l, t in reps.items():
+                        if not need_full:  # only the [B,E] means leave the device
+                            t = t[:, :1, :]
+                        host_reps[l] = pool.take(t)
+                        host_reps[l].copy_(t, non_blocking=True)
+                        host_means[l] = pool.take(means_dev[l])
+                        host_means[l].copy_(means_dev[l], non_blocking=True)
+                    if contacts is not None:
+                        host_contacts = pool.take(contacts)
+                        host_contacts.copy_(contacts, non_blocking=True)
+                    copied = torch.cuda.Event()
+                    copied.record(copy_stream)
+            else:  # async_host: the stub's CPU tensors are the "host copies"
+                host_reps = {l: t.contiguous() for l, t in reps.items()}
+                host_contacts = contacts
+                host_means = dict(means_dev)
 
-            def job(ids=ids, labels=labels, strs=strs, host_reps=host_reps, host_contacts=host_contacts, copied=copied,
-                    host_means=host_means, keep_alive=(reps, contacts, means_dev)):
-                copied.synchronize()
-                finish(ids, labels, strs, host_reps, host_contacts, {l: m.clone() for l, m in host_means.items()})
+            def chunk_job(rows, ids=ids, labels=labels, strs=strs, host_reps=host_reps, host_contacts=host_contacts,
+                          copied=copied, host_means=host_means):
+                if copied is not None:
+                    copied.synchronize()
+                finish(ids, labels, strs, host_reps, host_contacts, {l: m.clone() for l, m in host_means.items()}, rows)
+
+            def done(host_reps=host_reps, host_contacts=host_contacts, host_means=host_means,
+                     keep_alive=(reps, contacts, means_dev)):
+                if pool is None:
+                    return
                 for t in list(host_reps.values()) + list(host_means.values()):
                     pool.give(t)
                 if host_contacts is not None:
                     pool.give(host_contacts)
 
-            writer.submit(job)
+            step = max(1, int(chunk_rows))
+            writer.submit([(lambda r=range(a, min(a + step, len(ids))): chunk_job(r)) for a in range(0, len(ids), step)], done)
     if writer is not None:
         writer.close()
     gathered: Dict[int, torch.Tensor] = {}

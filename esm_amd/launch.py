@@ -34,6 +34,46 @@ def relaunch(n_ranks: int, target, argv) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def rank_cpu_slice(local_rank: int, local_world: int, cpus=None):
+    """CPUs for one rank of ``local_world`` ranks on this host: a contiguous 1 / local_world share of the allowed
+    hardware threads, hyper-thread siblings kept together (Linux numbers the second thread of core i as i + n_cores),
+    so that a rank's tokeniser, writer threads and the driver thread of its GPU stay on neighbouring cores (one NUMA
+    node when the shares align) instead of migrating over 256 threads."""
+    cpus = sorted(os.sched_getaffinity(0)) if cpus is None else sorted(cpus)
+    n = len(cpus)
+    if local_world <= 1 or n < 2 * local_world:
+        return set(cpus)
+    sib = {}
+    try:  # thread_siblings_list of the first allowed CPU tells the numbering scheme
+        with open(f"/sys/devices/system/cpu/cpu{cpus[0]}/topology/thread_siblings_list") as fh:
+            txt = fh.read().strip()
+        first = sorted(int(x) for part in txt.split(",") for x in (range(int(part.split("-")[0]), int(part.split("-")[-1]) + 1)))
+        if len(first) == 2 and first[1] - first[0] == n // 2 and set(range(cpus[0], cpus[0] + n)) == set(cpus):
+            sib = {c: c + n // 2 for c in cpus[: n // 2]}
+    except (OSError, ValueError):
+        pass
+    if sib:  # cores [a, b) and their siblings
+        cores = cpus[: n // 2]
+        per = len(cores) // local_world
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        return set(mine) | {sib[c] for c in mine}
+    per = n // local_world
+    return set(cpus[local_rank * per:(local_rank + 1) * per])
+
+
+def pin_rank_cpus(local_rank: int, local_world: int):
+    """Restrict this process (and the threads it starts) to its share of the host's CPUs.  ``ESM_AMD_NO_AFFINITY=1``
+    switches it off.  Returns the CPU set in effect."""
+    if os.environ.get("ESM_AMD_NO_AFFINITY", "0") == "1" or not hasattr(os, "sched_setaffinity"):
+        return set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set()
+    want = rank_cpu_slice(local_rank, local_world)
+    try:
+        os.sched_setaffinity(0, want)
+    except OSError:
+        pass
+    return set(os.sched_getaffinity(0))
+
+
 def init_ranks(expect_world: int, backend: str):
     """Join the launcher's process group.  Returns (dist or None, rank, world, local_rank); verifies that the world
     is the one asked for, that the backend is the one asked for, and that a collective actually works (an
@@ -48,6 +88,12 @@ def init_ranks(expect_world: int, backend: str):
     if not under_launcher():
         return None, 0, 1, 0
     import torch.distributed as dist
+
+    # one node: every rank gets its own share of the host's CPUs (tokeniser + writer threads + GPU driver thread)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cpus = pin_rank_cpus(local_rank, local_world)
+    if cpus:
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus))))
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")

@@ -66,6 +66,32 @@ def linear(a, w, bias=None, epilogue=N.EPI_STORE_T, out=None, force_generic=Fals
     return out
 
 
+def split_weight(w):
+    """w [N,K] (fp32 / fp16 / bf16) -> fp16 [N,2K]: 64-column K tiles interleaved hi | lo, hi = fp16(w), lo = fp16(w - hi)
+    (the weight image of the f16x2 precision mode)."""
+    _req_cuda(w)
+    Nn, K = w.shape
+    out = torch.zeros((Nn, 2 * K), dtype=torch.float16, device=w.device)
+    N.check(N.lib.esmk_op_split_weight(N.ptr(w.contiguous()), N.dtype_code(w.dtype), N.ptr(out), Nn, K, N.cur_stream()))
+    return out
+
+
+def linear_split(a, w2, bias=None, epilogue=N.EPI_STORE_T, out=None):
+    """a [M,K] fp16, w2 = split_weight(w) [N,2K]: a . (w_hi + w_lo)^T + bias with the epilogues of ``linear``."""
+    _req_cuda(a, w2, bias, out)
+    assert a.dtype == torch.float16 and w2.dtype == torch.float16
+    M, K = a.shape
+    Nn = w2.shape[0]
+    assert w2.shape[1] == 2 * K
+    if epilogue == N.EPI_RESID_F32:
+        assert out is not None and out.dtype == torch.float32 and tuple(out.shape) == (M, Nn)
+    elif out is None:
+        out = torch.empty((M, Nn), dtype=torch.float16 if epilogue in (N.EPI_STORE_T, N.EPI_GELU_T) else torch.float32,
+                          device=a.device)
+    N.check(N.lib.esmk_op_linear_split(N.ptr(a), N.ptr(w2), N.ptr(bias), N.ptr(out), M, Nn, K, epilogue, N.cur_stream()))
+    return out
+
+
 LOG2E = 1.4426950408889634
 
 

@@ -67,6 +67,11 @@ typedef struct esmk_config {
     int32_t num_positions;   /* > 0: rows of the LearnedPositionalEmbedding table added to the token embedding
                                 (esm1.py:133, modules.py:240-257); key "embed_positions.weight"   */
     int32_t ln_before;       /* 1: emb_layer_norm_before (esm1.py:136-137)                          */
+    /* Precision mode "f16x2" (operand_dtype must be ESMK_F16): the weight matrices of the layer stack are kept as
+     * W = W_hi + W_lo (two fp16 images, ~20 bits of every weight) and every layer GEMM runs both against the fp16
+     * activations — the weight rounding, two thirds of the fp16-operand error of a 33-layer stack,
+     * disappears at 2x the GEMM time.  Parameter image 2x larger.  0 = plain fp16 / bf16 operands. */
+    int32_t weight_split;
 } esmk_config;
 
 const char* esmk_last_error(void);
@@ -212,6 +217,14 @@ int esmk_debug_linear_splitk(const void* a_dev, const void* w_dev, float* partia
  * GEMM launch records s_memtime stamps per workgroup and tile, uint64 [256][32][4] =
  * {tile start, main loop done, epilogue done, unused}; NULL switches it off. */
 int esmk_debug_gemm_timing(void* stamps_dev);
+
+/* Split-weight GEMM of the f16x2 precision mode as single ops (tests, tools/bench_gemm9.py):
+ * esmk_op_split_weight: w [N,K] (any float dtype) -> w2 fp16 [N,2K], K tiles of 64 columns interleaved hi | lo with
+ * hi = fp16(w), lo = fp16(w - hi);  esmk_op_linear_split: out = a[M,K] . (w_hi + w_lo)^T + bias with the epilogues of
+ * esmk_op_linear (K % 64 == 0, N % 8 == 0). */
+int esmk_op_split_weight(const void* w_dev, int w_dtype, void* w2_dev, int N, int K, void* stream);
+int esmk_op_linear_split(const void* a_dev, const void* w2_dev, const float* bias_dev, void* out_dev, int M, int N, int K,
+                         int epilogue, void* stream);
 
 /* Measurement / A-B hook (no reference counterpart): which persistent GEMM kernel serves the dense nn.Linear calls
  * from now on — 8 = gemm8.hip (two waves per SIMD), 9 = gemm9.hip (one wave per SIMD, 128 x 128 wave blocks;

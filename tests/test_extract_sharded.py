@@ -97,5 +97,60 @@ def _worker(rank, world, port, tmp):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_extract_gloo(tmp_path, world):
-    port = 29600 + world + (os.getpid() % 200)
+    from esm_amd.launch import free_port
+
+    port = free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+
+
+def test_host_side_at_eight_ranks(tmp_path):
+    """8 ranks x (tokeniser + chunked writer threads) on ONE host, the real extract() pipeline
+    with the writer threads active (async_host) and a stub forward; every file written exactly once, the gathered
+    means right on every rank.  tools/bench_extract_hosts.py is the same harness at full size (5 MB files,
+    64 k-token batches, 100 ms per batch) for the GPU host's 256 threads; its number is quoted in DESIGN.md §6."""
+    import argparse
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_extract_hosts as bh
+
+    args = argparse.Namespace(world=8, seqs_per_rank=12, len=150, embed_dim=32, toks_per_batch=1024, gpu_ms=2.0,
+                              writer_threads=3, include=["mean", "per_tok"], out_root=str(tmp_path), no_affinity=False,
+                              check=True)
+    res = bh.run(args)
+    assert res["files"] == 96 and len(res["files_per_s_per_rank"]) == 8
+    assert res["files_per_s_total"] > 0
+
+
+def test_rank_cpu_slices_partition_the_host():
+    from esm_amd.launch import rank_cpu_slice
+
+    for n, world in ((256, 8), (64, 4), (8, 8), (6, 4)):
+        slices = [rank_cpu_slice(r, world, range(n)) for r in range(world)]
+        if n >= 2 * world:
+            assert all(len(s) == n // world for s in slices)
+            assert set().union(*slices) == set(range(n)) and sum(len(s) for s in slices) == n  # disjoint, complete
+        else:
+            assert all(s == set(range(n)) for s in slices)  # too few CPUs to split: everyone keeps all
+
+
+def test_writer_runs_a_batch_on_all_threads():
+    """a batch is several chunk jobs, so more than `depth` threads can work at once and `done` runs once."""
+    import threading
+    import time
+
+    from esm_amd.extract import _Writer
+
+    w = _Writer(depth=1, threads=4)
+    seen, done = set(), []
+    lock = threading.Lock()
+
+    def job():
+        with lock:
+            seen.add(threading.get_ident())
+        time.sleep(0.05)
+
+    w.submit([job] * 8, done=lambda: done.append(1))
+    w.submit([job] * 8, done=lambda: done.append(2))  # waits for the first batch's slot
+    w.close()
+    assert len(seen) == 4 and done == [1, 2]

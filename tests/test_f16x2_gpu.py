@@ -1,0 +1,79 @@
+"""The split-weight precision mode (ESM_AMD_OPERAND=f16x2, esmk_config.weight_split): every matrix of the layer stack
+is kept as W = W_hi + W_lo (two fp16 images) and each layer GEMM runs over both — the weight rounding, two thirds of
+the fp16-operand error of a deep stack, disappears at 2x the GEMM time.
+
+    * the split GEMM as a single op against fp64 (error ~1e-6 relative instead of ~2e-4);
+    * the 650M-dimension model against the fp32 oracle: representations, logits and raw token argmax inside 1e-3
+      (reference tolerance: tests/test_readme.py:116 atol=1e-3; north star: "token argmax bit-exact").
+"""
+import math
+
+import pytest
+import torch
+
+import esm
+from esm_amd import _native as nat
+from esm_amd import ops
+from esm_amd.synth import skip_param_init, synth_esm2_state_dict, synth_tokens
+from oracle.esm2_oracle import esm2_forward
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 256, 64), (1000, 1288, 320), (4096, 1280, 1280)])
+def test_linear_split_matches_fp64(M, N, K):
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn(M, K, device="cuda", generator=g).half()
+    w = torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)
+    bias = torch.randn(N, device="cuda", generator=g)
+    w2 = ops.split_weight(w)
+    # the image itself: hi + lo reproduces w to ~2^-19 of the weight scale
+    hi = w2.view(N, K // 64, 2, 64)[:, :, 0].reshape(N, K).float()
+    lo = w2.view(N, K // 64, 2, 64)[:, :, 1].reshape(N, K).float()
+    assert torch.equal(hi, w.half().float())
+    assert ((hi + lo) - w).abs().max().item() < 2.0 ** -18 * w.abs().max().item()
+    ref = a.double() @ w.double().t() + bias.double()
+    scale = ref.abs().max().item()
+    for epi in (nat.EPI_STORE_F32, nat.EPI_STORE_T, nat.EPI_RESID_F32):
+        x0 = torch.zeros(M, N, device="cuda") if epi == nat.EPI_RESID_F32 else None
+        got = ops.linear_split(a, w2, bias, epi, out=x0).double()
+        plain = ops.linear(a, w.half(), bias, epi, out=torch.zeros(M, N, device="cuda") if x0 is not None else None).double()
+        e_split, e_plain = (got - ref).abs().max().item() / scale, (plain - ref).abs().max().item() / scale
+        print(f"\n({M},{N},{K}) epi {epi}: split {e_split:.2e}, plain fp16 weights {e_plain:.2e}")
+        if epi == nat.EPI_STORE_T:
+            assert e_split < 6e-4  # the fp16 output rounding itself
+        else:
+            assert e_split < 1e-5 and e_plain > 8 * e_split, (e_split, e_plain)
+    # GELU epilogue against the same function in fp64
+    got = ops.linear_split(a, w2, bias, nat.EPI_GELU_T).double()
+    want = torch.nn.functional.gelu(ref)
+    assert (got - want).abs().max().item() < 1e-3 * want.abs().max().item()
+
+
+def test_650m_dims_split_weights_meet_the_contract(monkeypatch):
+    L, E, H = 33, 1280, 20
+    sd = synth_esm2_state_dict(L, E, H, seed=0)
+    toks = synth_tokens(2, 128, seed=100)
+    ref = esm2_forward({k: v.float() for k, v in sd.items()}, toks, L, H, repr_layers=[L])
+    with skip_param_init():
+        model = esm.ESM2(L, E, H).eval()
+    model.load_state_dict(sd)
+    model = model.cuda()
+    out = {}
+    for mode in ("f16", "f16x2"):
+        monkeypatch.setenv("ESM_AMD_OPERAND", mode)
+        with torch.no_grad():
+            o = model(toks.cuda(), repr_layers=[L])
+        r, rr = o["representations"][L].double().cpu(), ref["representations"][L].double()
+        lg, lgr = o["logits"].double().cpu(), ref["logits"].double()
+        out[mode] = dict(repr_max=((r - rr).abs().max() / rr.abs().max()).item(), repr_l2=((r - rr).norm() / rr.norm()).item(),
+                         logits=((lg - lgr).abs().max() / lgr.abs().max()).item(),
+                         argmax=(lg.argmax(-1) == lgr.argmax(-1)).float().mean().item())
+        print(f"\n650M dims {mode}: {out[mode]}")
+    monkeypatch.delenv("ESM_AMD_OPERAND")
+    s = out["f16x2"]
+    # emulated floor of the mode on these inputs (oracle, weights exact): 6.2e-4 max / 4.9e-4 L2, logits 8.5e-4
+    assert s["repr_max"] < 8e-4 and s["repr_l2"] < 6.5e-4, s
+    assert s["logits"] < 1e-3, s
+    assert s["argmax"] == 1.0, s
+    assert s["repr_l2"] < 0.7 * out["f16"]["repr_l2"], out

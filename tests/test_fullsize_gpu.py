@@ -92,7 +92,8 @@ def model_3b():
     return m.cuda()
 
 
-def _check_3b(model, name):
+def _check_3b(model, name, mode="f16"):
+    """mode "f16x2": the split-weight precision mode (ESM_AMD_OPERAND=f16x2 set by the caller) — tighter bounds."""
     fix = fixture(name)
     L = fix["dims"]["L"]
     toks = fix["tokens"].to(torch.int64)
@@ -115,12 +116,23 @@ def _check_3b(model, name):
                          contact_logit_rel=zrel, fused_vs_materialised=fperr)
     raw, decided_ok, lerr = argmax_check(out["logits"].float().cpu(), fix["logits"], nonpad)
     print(f"\n{name}: {report}; logits abs err {lerr:.2e}, argmax raw {raw:.4f}, decided ok {decided_ok}")
+    lrel = lerr / fix["logits"].abs().max().item()
+    print(f"{name} [{mode}]: logits rel {lrel:.2e}")
     for b, r in report.items():
-        assert r["repr_rel_l2"] < 1e-3, (b, r)          # the contract in the L2 sense
-        assert r["repr_rel_max"] < 1e-3, (b, r)         # the contract in the max norm as well (round-3 ruling: full-size fixtures keep hard bounds)
-        assert r["contact_logit_rel"] < 3e-3 and r["contact_prob"] < 1e-2, (b, r)
+        if mode == "f16x2":
+            # split weights: the emulated floor of this mode (weights exact, fp16 activations / q / k / v / P) is
+            # 5.1 - 6.7e-4 (max norm) / 4.9 - 5.6e-4 (L2) on 650M and 3B dimensions (profiles/r3_f16x2_cpu_study.log)
+            assert r["repr_rel_l2"] < 7e-4 and r["repr_rel_max"] < 8e-4, (b, r)
+            assert r["contact_logit_rel"] < 2e-3 and r["contact_prob"] < 1e-2, (b, r)
+        else:
+            assert r["repr_rel_l2"] < 1e-3, (b, r)          # the contract in the L2 sense
+            assert r["repr_rel_max"] < 1e-3, (b, r)         # the contract in the max norm as well (round-3 ruling: full-size fixtures keep hard bounds)
+            assert r["contact_logit_rel"] < 3e-3 and r["contact_prob"] < 1e-2, (b, r)
         assert r["fused_vs_materialised"] < 1e-4, (b, r)
+    if mode == "f16x2":
+        assert lrel < 1e-3, lrel  # the contract on the logits, which plain fp16 operands miss (1.4e-3)
     assert decided_ok and raw > 0.98
+    return report, lrel, raw
 
 
 @pytest.mark.gpu
@@ -131,6 +143,18 @@ def test_config3_3b_contacts_T258(model_3b):
 @pytest.mark.gpu
 def test_config3_3b_contacts_padded_1022_300(model_3b):
     _check_3b(model_3b, "esm2_3b_padded")
+
+
+@pytest.mark.gpu
+def test_config3_3b_T258_split_weight_mode(model_3b, monkeypatch):
+    """ESM_AMD_OPERAND=f16x2 (W = W_hi + W_lo, two MFMA passes per layer GEMM): representations AND logits inside
+    1e-3 with margin on the full-size config-3 fixture; the engine re-packs its weights when the mode changes."""
+    monkeypatch.setenv("ESM_AMD_OPERAND", "f16x2")
+    try:
+        report, lrel, raw = _check_3b(model_3b, "esm2_3b_T258", mode="f16x2")
+    finally:
+        monkeypatch.delenv("ESM_AMD_OPERAND")
+        model_3b.refresh_engine() if hasattr(model_3b, "refresh_engine") else None
 
 
 # ------------------------------------------------------------------------------------------------------------
