@@ -47,7 +47,9 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0        # spec; 6.29 TB/s is the measured copy ceiling
 HBM_ACHIEVABLE_GBS = 6300.0
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r2_pmc_summary.json")
+PMC_SUMMARY = {"esm2_650m": os.path.join(ROOT, "profiles", "r3_pmc_summary.json"),
+               "msa1b": os.path.join(ROOT, "profiles", "r3_pmc_summary_msa1b.json"),
+               "esm2_3b_contacts": os.path.join(ROOT, "profiles", "r3_pmc_summary_esm2_3b_contacts.json")}
 
 
 def argmax_report(logits, ref_logits):
@@ -155,12 +157,18 @@ def class_table(prof, prof_steps):
     }
 
 
-def pmc_traffic(kernel_class, src_hash):
-    """HBM bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes (tools/profile_bench.sh ->
-    profiles/r2_pmc_summary.json; FETCH_SIZE doubled as the microarch guide prescribes for gfx950).  The summary
-    records the source hash of the library it profiled: a different build -> null (never a stale number)."""
+# bench.py's class names -> the classes tools/pmc_summary.py can tell apart by kernel name (the q/k and the v
+# projection are two launches of one class here; the q/k launch is the larger one)
+PMC_CLASS = {"gemm_qkv_rope": "gemm_qkv_rope(qk)"}
+
+
+def pmc_traffic(kernel_class, src_hash, workload="esm2_650m"):
+    """HBM bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes of that workload (tools/
+    profile_bench.sh -> profiles/r3_pmc_summary*.json; FETCH_SIZE doubled as the microarch guide prescribes for
+    gfx950).  The summary records the source hash of the library it profiled: a different build -> null (never a
+    stale number)."""
     try:
-        with open(PMC_SUMMARY) as f:
+        with open(PMC_SUMMARY[workload]) as f:
             s = json.load(f)
         if s.get("library_src_hash") != src_hash:
             return None, f"PMC summary is from build {s.get('library_src_hash')}, this is {src_hash}"
@@ -203,7 +211,7 @@ def base_result(args, world, metric, value, elapsed, workload, extra_cfg):
     return {
         "metric": metric, "value": round(value, 1), "unit": "residues/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": operand_name(), "data": "synthetic",
+        "scaling": getattr(args, "scaling", "weak"), "vs_baseline": None, "dtype": operand_name(), "data": "synthetic",
         "config": {"workload": workload, "sharding": f"dp{world} (no data-path collective)", **extra_cfg},
         "host_cores": os.cpu_count(), "per_rank_ms_per_step": list(PER_RANK_MS),
     }
@@ -230,7 +238,12 @@ def run_esm2_650m(args, dist, rank, world, dev):
         model = esm.ESM2(L, E, H).eval()
     model.load_state_dict(sd)
     model = model.to(dev)
-    batch = args.batch or 64
+    if args.scaling == "strong":  # the node's work per step is fixed: 512 sequences (64 per GPU at N = 8)
+        total = args.batch or 512
+        assert total % world == 0, f"--scaling strong: --batch {total} must be a multiple of --gpus {world}"
+        batch = total // world
+    else:
+        batch = args.batch or 64
     toks = synth_tokens(batch, args.seq_len, seed=1 + rank).to(dev)  # each rank its own shard
     residues_per_step = batch * args.seq_len
 
@@ -360,10 +373,10 @@ def operand_floor_report(sd, toks_cpu, L, H, r_ref):
 # The other BASELINE configurations, so that the driver's default run records them too ("driver-visible numbers
 # for everything but config 2").  Each is the same `--workload` run a user would start, as a child process with a
 # time limit; nothing in here can cost the flagship line.
-SECONDARY = [
-    ("msa1b", ["--workload", "msa1b", "--no-cpu-baseline"], 120),
+SECONDARY = [  # --quick-baseline: the children's own CPU-oracle sample (parity + cpu_baseline), sized for a few seconds
+    ("msa1b", ["--workload", "msa1b", "--quick-baseline"], 120),
     ("extract_650m", ["--workload", "extract_650m", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"], 150),
-    ("esm2_3b_contacts", ["--workload", "esm2_3b_contacts", "--steps", "4", "--no-cpu-baseline"], 200),
+    ("esm2_3b_contacts", ["--workload", "esm2_3b_contacts", "--steps", "4", "--quick-baseline"], 200),
 ]
 T_PROCESS_START = time.perf_counter()
 SECONDARY_BUDGET_S = 180.0  # the default run, children included, ends within ~3 minutes of its start
@@ -380,7 +393,7 @@ def secondary_workloads(extra=(), budget_end=None):
            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_PORT",
                         "MASTER_ADDR", "TORCHELASTIC_RUN_ID", "ESM_AMD_BENCH_LAUNCH")}
     keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "e2e_mfma_frac_per_gpu",
-            "tflops_algorithmic", "config")
+            "tflops_algorithmic", "config", "parity", "cpu_baseline")
     out = {}
     for name, argv, limit in SECONDARY:
         t0 = time.perf_counter()
@@ -397,7 +410,8 @@ def secondary_workloads(extra=(), budget_end=None):
             r = json.loads(lines[-1])
             out[name] = {k: r[k] for k in keep if k in r}
             if isinstance(r.get("roofline"), dict):
-                out[name]["roofline"] = {k: r["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")}
+                out[name]["roofline"] = {k: r["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
+                                                                             "traffic", "traffic_source")}
         except Exception as e:  # a time limit, a crash, a malformed line: reported, never raised
             out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
         out[name]["wall_s"] = round(time.perf_counter() - t0, 1)
@@ -440,15 +454,18 @@ def run_esm2_3b_contacts(args, dist, rank, world, dev):
         f"{MODEL} predict_contacts(tokens [B,{T}]): 36-layer forward + contact head without the [B,L,H,T,T] tensor, "
         "random-init weights of the 3B architecture", {"batch_per_gpu": batch, "seq_len": args.seq_len})
     result["e2e_mfma_frac_per_gpu"] = round(value / world / args.seq_len * flop_per_seq / (MFMA_PEAK_TFLOPS * 1e12), 4)
-    _, result["roofline"] = mfma_roofline(prof)
+    dom, result["roofline"] = mfma_roofline(prof)
     result["roofline_hbm"] = hbm_roofline(prof)
     result["kernel_classes"] = class_table(prof, prof_steps)
     result["library"] = library_build()
+    result["roofline"]["traffic"], result["roofline"]["traffic_source"] = pmc_traffic(
+        PMC_CLASS.get(dom["name"], dom["name"]), result["library"]["src_hash"], "esm2_3b_contacts")
     if world == 1 and not args.no_cpu_baseline:
         from oracle.esm2_oracle import esm2_forward
 
         ncores = cpu_threads()
-        small = synth_tokens(1, 256, seed=5)  # bounded sample: the oracle materialises [1440,T,T] four times
+        n_small = 128 if args.quick_baseline else 256
+        small = synth_tokens(1, n_small, seed=5)  # bounded sample: the oracle materialises [1440,T,T] four times
         c0 = time.perf_counter()
         ref = esm2_forward(sd, small, L, H, repr_layers=[L], return_contacts=True)
         t_cpu = time.perf_counter() - c0
@@ -456,9 +473,9 @@ def run_esm2_3b_contacts(args, dist, rank, world, dev):
             got = model.predict_contacts(small.to(dev)).cpu()
         lg = lambda t: torch.logit(t.double().clamp(1e-12, 1 - 1e-12))
         z, zr = lg(got), lg(ref["contacts"])
-        result["cpu_baseline"] = {"value": round(256 / t_cpu, 1), "unit": "residues/s", "cores": ncores,
+        result["cpu_baseline"] = {"value": round(n_small / t_cpu, 1), "unit": "residues/s", "cores": ncores,
                                   "host_cores": os.cpu_count(), "kind": "port",
-                                  "sample": "one sequence of 256 residues through the fp32 oracle with contacts, 1 run"}
+                                  "sample": f"one sequence of {n_small} residues through the fp32 oracle with contacts, 1 run"}
         result["parity"] = {"contacts_max_abs_prob_diff": (got - ref["contacts"]).abs().max().item(),
                             "contacts_max_abs_logit_diff": (z - zr).abs().max().item(),
                             "contacts_logit_diff_rel_to_range": ((z - zr).abs().max() / zr.abs().max()).item()}
@@ -504,24 +521,27 @@ def run_msa1b(args, dist, rank, world, dev):
         "attention + column attention + FFN, random-init weights", {"msas_per_gpu": batch, "rows": R, "cols": C})
     result["e2e_mfma_frac_per_gpu"] = round(flop * args.steps / elapsed / (MFMA_PEAK_TFLOPS * 1e12), 4)
     result["tflops_algorithmic"] = round(flop * args.steps / elapsed / 1e12, 1)
-    _, result["roofline"] = mfma_roofline(prof)
+    dom, result["roofline"] = mfma_roofline(prof)
     result["roofline_hbm"] = hbm_roofline(prof)
     result["kernel_classes"] = class_table(prof, prof_steps)
     result["library"] = library_build()
+    result["roofline"]["traffic"], result["roofline"]["traffic_source"] = pmc_traffic(
+        PMC_CLASS.get(dom["name"], dom["name"]), result["library"]["src_hash"], "msa1b")
     if world == 1 and not args.no_cpu_baseline:
         from oracle.msa_oracle import msa_forward
 
         ncores = cpu_threads()
-        small = toks[:1, :32].cpu()  # bounded sample: a 32-row slice of the same MSA (depth changes the tied scale)
+        n_rows = 8 if args.quick_baseline else 32
+        small = toks[:1, :n_rows].cpu()  # bounded sample: a slice of the same MSA (depth changes the tied scale)
         c0 = time.perf_counter()
         ref = msa_forward(sd, small, L, H, repr_layers=[L])
         t_cpu = time.perf_counter() - c0
         with torch.no_grad():
             got = model(small.to(dev), repr_layers=[L])
         r_gpu, r_ref = got["representations"][L].cpu().double(), ref["representations"][L].double()
-        result["cpu_baseline"] = {"value": round(32 * (C - 1) / t_cpu, 1), "unit": "residues/s", "cores": ncores,
+        result["cpu_baseline"] = {"value": round(n_rows * (C - 1) / t_cpu, 1), "unit": "residues/s", "cores": ncores,
                                   "host_cores": os.cpu_count(), "kind": "port",
-                                  "sample": "the first 32 rows of the MSA (32 x 513) through the fp32 oracle, 1 run"}
+                                  "sample": f"the first {n_rows} rows of the MSA ({n_rows} x 513) through the fp32 oracle, 1 run"}
         result["parity"] = {"rel_repr_diff_vs_cpu": ((r_gpu - r_ref).abs().max() / r_ref.abs().max()).item(),
                             "rel_l2_repr_diff_vs_cpu": ((r_gpu - r_ref).norm() / r_ref.norm()).item(),
                             **argmax_report(got["logits"].float().cpu(), ref["logits"].float())}
@@ -617,6 +637,12 @@ def main():
                                                          "sequences for esm2_650m, 32 for esm2_3b_contacts, 1 MSA)")
     ap.add_argument("--seq-len", type=int, default=1022)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick-baseline", action="store_true",
+                    help="esm2_3b_contacts / msa1b: a smaller CPU-oracle sample (128 residues / 8 MSA rows), used by the "
+                         "default run's child processes to stay inside its time budget")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="esm2_650m with --gpus N: weak = --batch sequences per GPU (default), strong = --batch sequences "
+                         "in total per step (default 512), split over the GPUs")
     ap.add_argument("--no-secondary", action="store_true",
                     help="esm2_650m at N = 1: do not append the other workloads (msa1b, esm2_3b_contacts, extract_650m; "
                          "child runs, ~2 min) as `secondary_workloads`; --no-cpu-baseline implies it")

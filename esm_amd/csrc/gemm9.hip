@@ -124,96 +124,124 @@ ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x16 (&acc)[2][2][4], int m_bas
 // operand-dtype outputs (EPI_STORE_T, EPI_GELU_T, EPI_QKV_ROPE): 8 rounds of 32 rows x 64 columns.  A round's 8 KiB
 // fp32 image has 256-byte rows, 16-byte chunk c of row r at slot c ^ (r & 7): conflict free for the quad writes
 // (8 lanes = 8 rows of one chunk) and for the row-major reads (16 lanes = 16 different chunks).
+// Software pipeline over the rounds: the LDS executes a wave's accesses in order, so round r+1's writes are issued
+// right behind round r's reads and land while round r's values go through GELU / RoPE / the conversion — a single
+// wave has no partner to hide the LDS round trip behind (15.7k -> cycles of the first version were half latency).
 template <typename T, int EPI, bool FULL>
 ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x16 (&acc)[2][2][4], int m_base, int n_base, int lane, char* wl) {
     using V8 = typename Op<T>::v8;
     const int h = lane >> 5, lm = lane & 31;
     if constexpr (!FULL)
         if (m_base >= p.M) return;  // wave uniform
+    auto write_round = [&](int r) ESMK_INL {
+        const int hf = r >> 2, i = r & 3;
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        const int nb = n_base + 64 * hf;
-        if constexpr (!FULL)
-            if (nb >= p.N) continue;  // wave uniform
+        for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+            for (int g = 0; g < 4; ++g) {
+                const int chunk = 8 * j2 + 2 * g + h;
+                *reinterpret_cast<f32x4*>(wl + lm * 256 + ((chunk ^ (lm & 7)) << 4)) =
+                    f32x4{acc[hf][j2][i][4 * g], acc[hf][j2][i][4 * g + 1], acc[hf][j2][i][4 * g + 2], acc[hf][j2][i][4 * g + 3]};
+            }
+    };
+    // raw[k]: STORE / GELU: slot k / 2 (row (64 (k/2) + lane) / 8, columns 8 (lane & 7) ..), chunk k & 1;
+    //         RoPE: slot k / 4 (row (64 (k/4) + lane) / 4, dims 8 (lane & 3) ..), chunks {first half e2 0, 1; second half e2 0, 1}
+    auto read_round = [&](f32x4 (&raw)[8]) ESMK_INL {
+        if constexpr (EPI == EPI_QKV_ROPE) {
 #pragma unroll
-            for (int j2 = 0; j2 < 2; ++j2)
+            for (int it = 0; it < 2; ++it) {
+                const int slot = it * 64 + lane;
+                const int r = slot >> 2, g4 = slot & 3;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int chunk = 8 * j2 + 2 * g + h;
-                    *reinterpret_cast<f32x4*>(wl + lm * 256 + ((chunk ^ (lm & 7)) << 4)) =
-                        f32x4{acc[hf][j2][i][4 * g], acc[hf][j2][i][4 * g + 1], acc[hf][j2][i][4 * g + 2], acc[hf][j2][i][4 * g + 3]};
-                }
-            if constexpr (EPI == EPI_QKV_ROPE) {
-                // the 64 columns are one head (head_dim 64): dims d and d + 32 rotate together
-                // (multihead_attention.py:261 q scaling, rotary_embedding.py:11-20 x*cos + rotate_half(x)*sin)
-                const int which = nb / p.E;  // 0 q, 1 k (wave uniform)
-                const int head = (nb - which * p.E) >> 6;
-                T* qk = reinterpret_cast<T*>(which == 0 ? p.q : p.k);
-                const float sc = which == 0 ? p.scaling : 1.0f;
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const int slot = it * 64 + lane;
-                    const int r = slot >> 2, g4 = slot & 3;  // row of the round, dims [8 g4, 8 g4 + 8)
-                    float a1[8], a2[8];
-#pragma unroll
-                    for (int e2 = 0; e2 < 2; ++e2) {
-                        const f32x4 u = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((2 * g4 + e2) ^ (r & 7)) << 4));
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((8 + 2 * g4 + e2) ^ (r & 7)) << 4));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) a1[4 * e2 + e] = u[e], a2[4 * e2 + e] = w[e];
-                    }
-                    const int mm = m_base + 32 * i + r;
-                    const int m = FULL ? mm : min(mm, p.M - 1);
-                    const int b = m / p.T, tt = m - b * p.T;
-                    float y1[8], y2[8];
-#pragma unroll
-                    for (int e2 = 0; e2 < 2; ++e2) {
-                        const f32x4 c = *reinterpret_cast<const f32x4*>(p.cos + (size_t)tt * 32 + 8 * g4 + 4 * e2);
-                        const f32x4 s = *reinterpret_cast<const f32x4*>(p.sin + (size_t)tt * 32 + 8 * g4 + 4 * e2);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            // the contraction hipcc chose for epilogue8's `a1*c - a2*s`, `a2*c + a1*s`, spelled out:
-                            // bit-identical q / k whichever kernel ran (packed == padded == alone stays exact)
-                            const float x1 = a1[4 * e2 + e] * sc;
-                            const float x2 = a2[4 * e2 + e] * sc;
-                            y1[4 * e2 + e] = __builtin_fmaf(x1, c[e], -(x2 * s[e]));
-                            y2[4 * e2 + e] = __builtin_fmaf(x2, c[e], x1 * s[e]);
-                        }
-                    }
-                    V8 o1, o2;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o1[e] = Op<T>::from(y1[e]), o2[e] = Op<T>::from(y2[e]);
-                    if (FULL || mm < p.M) {
-                        T* dst = qk + ((size_t)(b * p.H + head) * p.T + tt) * 64 + 8 * g4;
-                        *reinterpret_cast<V8*>(dst) = o1;
-                        *reinterpret_cast<V8*>(dst + 32) = o2;
-                    }
-                }
-            } else {
-                T* out = reinterpret_cast<T*>(p.out);
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int slot = it * 64 + lane;
-                    const int r = slot >> 3, c8 = slot & 7;  // row of the round, columns [8 c8, 8 c8 + 8)
-                    float v[8];
-#pragma unroll
-                    for (int e2 = 0; e2 < 2; ++e2) {
-                        const f32x4 u = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((2 * c8 + e2) ^ (r & 7)) << 4));
-                        float t4[4] = {u[0], u[1], u[2], u[3]};
-                        if constexpr (EPI == EPI_GELU_T) gelu_fast_x4(t4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[4 * e2 + e] = t4[e];
-                    }
-                    V8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = Op<T>::from(v[e]);
-                    const int m = m_base + 32 * i + r, n = nb + 8 * c8;
-                    if (FULL || (m < p.M && n < p.N)) *reinterpret_cast<V8*>(out + (size_t)m * p.N + n) = o;
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    raw[4 * it + e2] = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((2 * g4 + e2) ^ (r & 7)) << 4));
+                    raw[4 * it + 2 + e2] = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((8 + 2 * g4 + e2) ^ (r & 7)) << 4));
                 }
             }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int slot = it * 64 + lane;
+                const int r = slot >> 3, c8 = slot & 7;
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2)
+                    raw[2 * it + e2] = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((2 * c8 + e2) ^ (r & 7)) << 4));
+            }
         }
+    };
+    auto finish_round = [&](int rd, const f32x4 (&raw)[8]) ESMK_INL {
+        const int hf = rd >> 2, i = rd & 3;
+        const int nb = n_base + 64 * hf;
+        if constexpr (!FULL)
+            if (nb >= p.N) return;  // wave uniform
+        if constexpr (EPI == EPI_QKV_ROPE) {
+            // the 64 columns are one head (head_dim 64): dims d and d + 32 rotate together
+            // (multihead_attention.py:261 q scaling, rotary_embedding.py:11-20 x*cos + rotate_half(x)*sin)
+            const int which = nb / p.E;  // 0 q, 1 k (wave uniform)
+            const int head = (nb - which * p.E) >> 6;
+            T* qk = reinterpret_cast<T*>(which == 0 ? p.q : p.k);
+            const float sc = which == 0 ? p.scaling : 1.0f;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int slot = it * 64 + lane;
+                const int r = slot >> 2, g4 = slot & 3;  // row of the round, dims [8 g4, 8 g4 + 8)
+                const int mm = m_base + 32 * i + r;
+                const int m = FULL ? mm : min(mm, p.M - 1);
+                const int b = m / p.T, tt = m - b * p.T;
+                float y1[8], y2[8];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.cos + (size_t)tt * 32 + 8 * g4 + 4 * e2);
+                    const f32x4 s = *reinterpret_cast<const f32x4*>(p.sin + (size_t)tt * 32 + 8 * g4 + 4 * e2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // the contraction hipcc chose for epilogue8's `a1*c - a2*s`, `a2*c + a1*s`, spelled out:
+                        // bit-identical q / k whichever kernel ran (packed == padded == alone stays exact)
+                        const float x1 = raw[4 * it + e2][e] * sc;
+                        const float x2 = raw[4 * it + 2 + e2][e] * sc;
+                        y1[4 * e2 + e] = __builtin_fmaf(x1, c[e], -(x2 * s[e]));
+                        y2[4 * e2 + e] = __builtin_fmaf(x2, c[e], x1 * s[e]);
+                    }
+                }
+                V8 o1, o2;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o1[e] = Op<T>::from(y1[e]), o2[e] = Op<T>::from(y2[e]);
+                if (FULL || mm < p.M) {
+                    T* dst = qk + ((size_t)(b * p.H + head) * p.T + tt) * 64 + 8 * g4;
+                    *reinterpret_cast<V8*>(dst) = o1;
+                    *reinterpret_cast<V8*>(dst + 32) = o2;
+                }
+            }
+        } else {
+            T* out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int slot = it * 64 + lane;
+                const int r = slot >> 3, c8 = slot & 7;  // row of the round, columns [8 c8, 8 c8 + 8)
+                float v[8];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    float t4[4] = {raw[2 * it + e2][0], raw[2 * it + e2][1], raw[2 * it + e2][2], raw[2 * it + e2][3]};
+                    if constexpr (EPI == EPI_GELU_T) gelu_fast_x4(t4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * e2 + e] = t4[e];
+                }
+                V8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = Op<T>::from(v[e]);
+                const int m = m_base + 32 * i + r, n = nb + 8 * c8;
+                if (FULL || (m < p.M && n < p.N)) *reinterpret_cast<V8*>(out + (size_t)m * p.N + n) = o;
+            }
+        }
+    };
+    write_round(0);
+#pragma unroll
+    for (int rd = 0; rd < 8; ++rd) {
+        f32x4 raw[8];
+        read_round(raw);
+        if (rd + 1 < 8) write_round(rd + 1);
+        __builtin_amdgcn_sched_barrier(0);  // the next round's LDS traffic is issued before this round's arithmetic
+        finish_round(rd, raw);
     }
 }
 
@@ -337,30 +365,26 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
 
     f32x16 acc[2][2][4];  // [64-column half][32-column block][32-row block]
     // bv[j]: bias broadcast of 32-column block j (the C operand of a tile's first MFMAs: acc = bias + A.W^T, the order
-    // gemm8 uses).  Column n = n_base + 32 j + 8 (r >> 2) + 4 (lane >> 5) + (r & 3) sits in register r.  Scalar loads through
-    // the constant address space: they do not enter the vmcnt queue.  EPI_V_T: the bias varies with the lane, its
-    // epilogue adds it.
-    typedef const __attribute__((address_space(4))) float* cfloat_ptr;
+    // gemm8 uses).  Column n = n_base + 32 j + 8 (r >> 2) + 4 (lane >> 5) + (r & 3) sits in register r.  EPI_V_T: the
+    // bias varies with the lane, its epilogue adds it.
     f32x16 bv[4];
-    auto init_bias = [&](int n_base) ESMK_INL {
+    // Vector loads (each lane fetches the 4 consecutive columns a register quad holds): issued BEFORE the previous
+    // tile's epilogue, so they land under it — the scalar-load form cost ~2k cycles of serialized waits per tile seam.
+    auto load_bias = [&](int n_base) ESMK_INL {
         bool done = false;
         if constexpr (EPI != EPI_V_T) {
             if (p.bias != nullptr) {
                 const int hsel = lane >> 5;
                 if (n_base + 128 <= p.N) {
-                    cfloat_ptr cb = (cfloat_ptr)(unsigned long long)(p.bias + n_base);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
+                            const f32x4 t = *reinterpret_cast<const f32x4*>(p.bias + n_base + 32 * j + 8 * g + 4 * hsel);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float b0 = cb[32 * j + 8 * g + e], b1 = cb[32 * j + 8 * g + 4 + e];
-                                bv[j][4 * g + e] = hsel ? b1 : b0;
-                            }
-                            __builtin_amdgcn_sched_barrier(0);  // 8 SGPRs at a time
+                            for (int e = 0; e < 4; ++e) bv[j][4 * g + e] = t[e];
                         }
-                } else {  // N tail: clamped vector loads
+                } else {  // N tail: clamped loads
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -449,16 +473,31 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
         }
     };
 
+    {
+        int tmi, tni;
+        tile_coords(0, tmi, tni);
+        load_bias(tni * 256 + wc * 128);
+    }
     for (int it = 0; it < n_my; ++it) {
         int tmi, tni;
         tile_coords(it, tmi, tni);
         const int m_base = tmi * 256 + wr * 128, n_base = tni * 256 + wc * 128;
-        init_bias(n_base);
         stamp(it, 0);
         ktile(true);
 #pragma unroll 1
         for (int kt = 1; kt < nk; ++kt) ktile(false);
         stamp(it, 1);
+        // the next tile's bias (bv is dead by now): on its way while this tile's epilogue runs where the epilogue
+        // leaves 64 registers free, right behind the epilogue otherwise
+        constexpr bool BIAS_EARLY = (EPI == EPI_STORE_T || EPI == EPI_GELU_T);
+        auto next_bias = [&]() ESMK_INL {
+            if (it + 1 < n_my) {
+                int tm2, tn2;
+                tile_coords(it + 1, tm2, tn2);
+                load_bias(tn2 * 256 + wc * 128);
+            }
+        };
+        if constexpr (BIAS_EARLY) next_bias();
         char* slice = smem + Q_EPI + wave * Q_SLICE;
         const bool full = (m_base + 128 <= p.M) && (n_base + 128 <= p.N);
         if constexpr (NO_EPI) {
@@ -483,6 +522,7 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
             if (full) epilogue9_t<T, EPI, true>(p, acc, m_base, n_base, lane, slice);
             else epilogue9_t<T, EPI, false>(p, acc, m_base, n_base, lane, slice);
         }
+        if constexpr (!BIAS_EARLY) next_bias();
         stamp(it, 2);
     }
     wait_vmcnt0();  // the trailing (dummy) DMA writes must land before the LDS is released

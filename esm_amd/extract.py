@@ -329,7 +329,8 @@ def extract(dataset, alphabet, embed_fn: Callable[[torch.Tensor, List[int], bool
                     pool.give(host_contacts)
 
             step = max(1, int(chunk_rows))
-            writer.submit([(lambda r=range(a, min(a + step, len(ids))): chunk_job(r)) for a in range(0, len(ids), step)], done)
+            # (chunk_job is bound NOW: the name is re-bound by the next batch before the writer threads run)
+            writer.submit([(lambda r=range(a, min(a + step, len(ids))), f=chunk_job: f(r)) for a in range(0, len(ids), step)], done)
     if writer is not None:
         writer.close()
     gathered: Dict[int, torch.Tensor] = {}

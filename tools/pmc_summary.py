@@ -20,11 +20,19 @@ sys.path.insert(0, ROOT)
 EPI_CLASS = {"2": "gemm_fc1_gelu", "5": "gemm_qkv_rope(qk)", "6": "gemm_qkv_rope(v)", "3": "lm_head_dense", "1": "lm_head_logits"}
 
 
+HAS_G9_RESID = False  # the profiled run sent the long-K residual GEMM (fc2) to gemm9, the out projection to gemm8
+
+
 def classify(name, nth_epi4):
-    m = re.search(r"gemm8_kernelI(?:DF16_|DF16b)Li(\d+)E", name)
+    m = re.search(r"gemm([89])_kernelI(?:DF16_|DF16b)Li(\d+)E", name)
     if m:
-        epi = m.group(1)
-        if epi == "4":  # out_proj and fc2 alternate in launch order inside every layer
+        epi = m.group(2)
+        if epi == "4":
+            if m.group(1) == "9":
+                return "gemm_fc2"
+            if HAS_G9_RESID:
+                return "gemm_out_proj"
+            # one kernel for both: out_proj and fc2 alternate in launch order inside every layer
             return "gemm_out_proj" if nth_epi4 % 2 == 0 else "gemm_fc2"
         return EPI_CLASS.get(epi, "gemm_epi" + epi)
     for key, cls in (("attn_fwd", "attention"), ("layernorm_kernel", "layernorm"), ("attn_probs", "attention_probs"),
@@ -34,7 +42,7 @@ def classify(name, nth_epi4):
     return None
 
 
-def main(out_path, dbs):
+def main(out_path, dbs, workload="esm2_650m"):
     acc = defaultdict(lambda: defaultdict(list))
     for path in dbs:
         c = sqlite3.connect(path)
@@ -42,13 +50,15 @@ def main(out_path, dbs):
         order = next((x for x in ("dispatch_id", "start", "id") if x in cols), None)
         q = "select kernel_name, counter_name, value, duration" + (f", {order}" if order else "") + " from counters_collection"
         rows = c.execute(q + (f" order by {order}" if order else "")).fetchall()
+        global HAS_G9_RESID
+        HAS_G9_RESID = any(re.search(r"gemm9_kernelI(?:DF16_|DF16b)Li4E", r[0]) for r in rows)
         seen = {}  # (dispatch key) -> class: every counter of one dispatch gets the same class
         n4 = defaultdict(int)
         for r in rows:
             name, ctr, val, dur = r[:4]
             key = (r[4] if order else None, name)
             if key not in seen or order is None:
-                is4 = re.search(r"gemm8_kernelI(?:DF16_|DF16b)Li4E", name) is not None
+                is4 = re.search(r"gemm8_kernelI(?:DF16_|DF16b)Li4E", name) is not None and not HAS_G9_RESID
                 seen[key] = classify(name, n4[ctr] if order is None else n4["_"])
                 if is4:
                     n4[ctr if order is None else "_"] += 1
@@ -84,9 +94,16 @@ def main(out_path, dbs):
     json.dump({"source": "tools/profile_bench.sh on MI355X (bench.py --steps 2 --warmup 1 --no-cpu-baseline; one rocprofv3 "
                          "--pmc pass per counter group)",
                "note": "hbm_bytes_corrected = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch (gfx950 FETCH_SIZE correction)",
-               "library_src_hash": library_hash(), "git_sha": sha, "kernels": kernels}, open(out_path, "w"), indent=1)
+               "workload": workload, "library_src_hash": library_hash(), "git_sha": sha, "kernels": kernels},
+              open(out_path, "w"), indent=1)
     print(json.dumps(kernels, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2:])
+    argv = sys.argv[1:]
+    wl = "esm2_650m"
+    if "--workload" in argv:
+        i = argv.index("--workload")
+        wl = argv[i + 1]
+        del argv[i:i + 2]
+    main(argv[0], argv[1:], wl)

@@ -4,7 +4,7 @@ import re, sqlite3, sys
 from collections import defaultdict
 
 def short(n):
-    m = re.search(r"(gemm8_kernel|gemm256_kernel|gemm64_kernel|attn_fwd_kernel|attn_probs_kernel|layernorm_kernel)I([A-Za-z0-9_]*?)E", n)
+    m = re.search(r"(gemm8_kernel|gemm9_kernel|gemm32_kernel|gemm256_kernel|gemm64_kernel|attn_fwd_kernel|attn_probs_kernel|layernorm_kernel)I([A-Za-z0-9_]*?)E", n)
     if m:
         return m.group(1) + "<" + m.group(2).replace("DF16_", "f16,").replace("DF16b", "bf16,").replace("Li", "") + ">"
     return re.sub(r"\(.*", "", n)[:60]
