@@ -102,12 +102,17 @@ SIGNATURES = {
     ),
     "esmk_debug_gemm_timing": (c_int, [c_void_p]),
     "esmk_debug_gemm_impl": (c_int, [c_int, c_int]),
+    "esmk_debug_mma_selftest": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "esmk_op_split_weight": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "esmk_op_linear_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "esmk_debug_linear_splitk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "esmk_op_qkv_rope": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    ),
+    "esmk_op_qkv_rope2": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     ),
     "esmk_op_attention": (
         c_int,

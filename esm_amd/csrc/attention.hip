@@ -402,6 +402,41 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
     if (lse != nullptr && h == 0 && qrow < Tseg) lse[rbase + qrow] = wave_active ? m_off + log2f(ltot) : 0.f;
 }
 
+// Self-test of Op<T>::mma_keep_c (common.h): the inline-asm MFMA with an early-clobber destination that keeps its C
+// operand intact.  hipcc's hazard recognizer does not look inside an asm statement, so the wait states around it are
+// hand counted; this kernel runs it next to the builtin on the same operands, with VALU writes of C right before it
+// and a dependent MFMA right after it (the attention kernel's pattern), and stores both results and C.
+template <typename T>
+__global__ void mma_keep_c_selftest_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ c0,
+                                           float* __restrict__ out) {
+    using V8 = typename Op<T>::v8;
+    const int lane = threadIdx.x;
+    const V8 af = *reinterpret_cast<const V8*>(a + lane * 8), bf = *reinterpret_cast<const V8*>(b + lane * 8);
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = c0[lane * 16 + r] * 2.0f;  // VALU writes of C just before the asm MFMA
+    f32x16 d_asm = Op<T>::mma_keep_c(af, bf, c);
+    d_asm = Op<T>::mma(af, bf, d_asm);                              // dependent builtin MFMA (SrcC = D of the asm one)
+    f32x16 d_ref = Op<T>::mma(af, bf, c);
+    d_ref = Op<T>::mma(af, bf, d_ref);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        out[(0 * 64 + lane) * 16 + r] = d_asm[r];
+        out[(1 * 64 + lane) * 16 + r] = d_ref[r];
+        out[(2 * 64 + lane) * 16 + r] = c[r];
+    }
+}
+
+hipError_t launch_mma_keep_c_selftest(const void* a, const void* b, const float* c, float* out, int operand_dtype,
+                                      hipStream_t st) {
+    if (operand_dtype == ESMK_DT_F16)
+        hipLaunchKernelGGL(mma_keep_c_selftest_kernel<_Float16>, dim3(1), dim3(64), 0, st, (const _Float16*)a, (const _Float16*)b, c, out);
+    else if (operand_dtype == ESMK_DT_BF16)
+        hipLaunchKernelGGL(mma_keep_c_selftest_kernel<__bf16>, dim3(1), dim3(64), 0, st, (const __bf16*)a, (const __bf16*)b, c, out);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 static hipError_t launch_attention_impl(const void* q, const void* k, const void* vt, const float* key_bias,
                                         const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
                                         int operand_dtype, int fill_mode, const int* any_pad, hipStream_t st,

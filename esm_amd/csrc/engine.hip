@@ -1002,15 +1002,22 @@ int esmk_debug_gemm_timing(void* stamps_dev) {
     return 0;
 }
 
+int esmk_debug_mma_selftest(const void* a_dev, const void* b_dev, const float* c_dev, float* out_dev, int operand_dtype,
+                            void* stream) {
+    if (!a_dev || !b_dev || !c_dev || !out_dev) return fail("esmk_debug_mma_selftest: null argument");
+    ESMK_TRY(launch_mma_keep_c_selftest(a_dev, b_dev, c_dev, out_dev, operand_dtype, (hipStream_t)stream));
+    return 0;
+}
+
 int esmk_debug_gemm_impl(int impl, int variant) {
     if (impl != 8 && impl != 9 && impl != 0) return fail("esmk_debug_gemm_impl: impl must be 8, 9 or 0 (automatic choice)");
     gemm_set_impl(impl, variant);
     return 0;
 }
 
-int esmk_op_qkv_rope(esmk_model* m, const void* a_dev, const void* wqkv_dev,
-                     const float* bias_dev, void* q_out, void* k_out, void* vt_out, int B, int T,
-                     void* stream) {
+int esmk_op_qkv_rope2(esmk_model* m, const void* a_dev, const void* wqkv_dev,
+                      const float* bias_dev, void* q_out, void* k_out, void* vt_out, int B, int T,
+                      int log2_domain, void* stream) {
     if (!m) return fail("esmk_op_qkv_rope: null model");
     if (m->D != 64 || m->Kp != m->E) return fail("esmk_op_qkv_rope: single-op entry point needs head_dim 64");
     hipStream_t st = (hipStream_t)stream;
@@ -1035,13 +1042,20 @@ int esmk_op_qkv_rope(esmk_model* m, const void* a_dev, const void* wqkv_dev,
     g.H = m->H;
     g.E = m->E;
     g.Tp = Tp;
-    g.scaling = 1.0f / sqrtf((float)m->D);
+    // log2_domain: q also carries log2(e), the form esmk_op_attention / esmk_op_attention_probs take (esmk_forward's own)
+    g.scaling = (log2_domain ? kLog2e : 1.0f) / sqrtf((float)m->D);
     ESMK_TRY(launch_gemm(g, EPI_QKV_ROPE, m->cfg.operand_dtype, st));
     g.W = (const char*)wqkv_dev + (size_t)2 * m->E * m->E * op_size(m->cfg.operand_dtype);
     g.bias = bias_dev + 2 * m->E;
     g.N = m->E;
     ESMK_TRY(launch_gemm(g, EPI_V_T, m->cfg.operand_dtype, st));
     return 0;
+}
+
+int esmk_op_qkv_rope(esmk_model* m, const void* a_dev, const void* wqkv_dev,
+                     const float* bias_dev, void* q_out, void* k_out, void* vt_out, int B, int T,
+                     void* stream) {
+    return esmk_op_qkv_rope2(m, a_dev, wqkv_dev, bias_dev, q_out, k_out, vt_out, B, T, 0, stream);
 }
 
 int esmk_op_attention(const void* q_dev, const void* k_dev, const void* vt_dev,

@@ -164,6 +164,10 @@ hipError_t launch_packed_stats(const int64_t* tokens, const int* seg, int n_seg,
 hipError_t launch_zero_gap_rows(void* buf, const int* seg, int n_seg, int rows, size_t row_bytes, hipStream_t st);
 
 // ---- attention.hip ---------------------------------------------------------------------
+// toolchain guard: the inline-asm MFMA of common.h (mma_keep_c) against the builtin; a, b [64 lanes][8] operand dtype,
+// c [64][16] fp32, out [3][64][16] = {asm path, builtin path, C after the calls}
+hipError_t launch_mma_keep_c_selftest(const void* a, const void* b, const float* c, float* out, int operand_dtype,
+                                      hipStream_t st);
 // query-block work list of a token-packed batch: work[4i..4i+3] = (first row of the segment, segment length,
 // first query of block i relative to the segment, segment index); npad[s] = <pad> tokens inside segment s
 struct AttnSegs {

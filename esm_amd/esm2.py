@@ -149,7 +149,8 @@ def warn_if_grad_expected(model):
                 "esm_amd: the MI355X engine is forward-only — the tensors returned by forward() have no grad_fn, so "
                 "backward() through this model yields no parameter gradients. Wrap inference in torch.no_grad() or "
                 "call model.requires_grad_(False) to silence this warning.", RuntimeWarning, stacklevel=3)
-        object.__setattr__(model, "_warned_no_grad", True)
+            # only once the warning was actually emitted: a later model.requires_grad_(True) must still be told
+            object.__setattr__(model, "_warned_no_grad", True)
 
 
 class _Engine:

@@ -177,15 +177,16 @@ class QkvHandle:
         N.check(N.lib.esmk_set_rope_inv_freq(self.h, arr, inv.numel()))
         self.E, self.H, self.dtype = embed_dim, num_heads, operand_dtype
 
-    def __call__(self, a, wqkv, bias, B, T):
+    def __call__(self, a, wqkv, bias, B, T, log2_domain=False):
+        """log2_domain: q also carries log2(e) — the q ``attention`` / ``attention_probs`` take (esmk_op_qkv_rope2)."""
         _req_cuda(a, wqkv, bias)
         H, dev = self.H, a.device
         Tp = (T + 63) // 64 * 64
         q = torch.empty((B, H, T, 64), dtype=self.dtype, device=dev)
         k = torch.empty_like(q)
         vt = torch.empty((B, H, 64, Tp), dtype=self.dtype, device=dev)
-        N.check(N.lib.esmk_op_qkv_rope(self.h, N.ptr(a), N.ptr(wqkv), N.ptr(bias), N.ptr(q), N.ptr(k), N.ptr(vt),
-                                       B, T, N.cur_stream()))
+        N.check(N.lib.esmk_op_qkv_rope2(self.h, N.ptr(a), N.ptr(wqkv), N.ptr(bias), N.ptr(q), N.ptr(k), N.ptr(vt),
+                                        B, T, int(bool(log2_domain)), N.cur_stream()))
         return q, k, vt
 
     def __del__(self):

@@ -30,7 +30,9 @@ ESM2_DIMS = {
 def skip_param_init():
     """Construct a model WITHOUT the random fill that nn.Linear / nn.LayerNorm / nn.Embedding constructors give their
     parameters (28 s for the 3B architecture on 8 threads) when a strict ``load_state_dict`` of a complete synthetic
-    state dict follows right away — which is what checks that nothing stays uninitialised.  Bench and tests only."""
+    state dict follows right away — which is what checks that nothing stays uninitialised.  Bench and tests only: it
+    patches ``reset_parameters`` of the three classes PROCESS-WIDE for the duration of the block, so it is not thread
+    safe and must not wrap the construction of modules that are not fully overwritten afterwards."""
     import torch.nn as nn
 
     classes = (nn.Linear, nn.LayerNorm, nn.Embedding)

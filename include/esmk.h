@@ -226,6 +226,14 @@ int esmk_op_split_weight(const void* w_dev, int w_dtype, void* w2_dev, int N, in
 int esmk_op_linear_split(const void* a_dev, const void* w2_dev, const float* bias_dev, void* out_dev, int M, int N, int K,
                          int epilogue, void* stream);
 
+/* Toolchain guard (no reference counterpart): the attention / contact kernels issue one MFMA per key tile through inline
+ * asm (its C operand, the softmax offset broadcast, must survive); the compiler does not see that instruction's hazards.
+ * Runs it beside the builtin on the same operands: a, b [64][8] operand dtype, c [64][16] fp32, out [3][64][16] fp32 =
+ * {asm path, builtin path, c after the calls}; the first two must be bit-equal, the third equal to 2 c
+ * (tests/test_kernels_gpu.py runs it on every GPU test run, i.e. on every toolchain the library is built with). */
+int esmk_debug_mma_selftest(const void* a_dev, const void* b_dev, const float* c_dev, float* out_dev, int operand_dtype,
+                            void* stream);
+
 /* Measurement / A-B hook (no reference counterpart): which persistent GEMM kernel serves the dense nn.Linear calls
  * from now on — 8 = gemm8.hip (two waves per SIMD), 9 = gemm9.hip (one wave per SIMD, 128 x 128 wave blocks;
  * bit-identical results) wherever it applies, 0 = the library's own choice per call (default).  `variant` selects a
@@ -240,6 +248,12 @@ int esmk_debug_gemm_impl(int impl, int variant);
 int esmk_op_qkv_rope(esmk_model* m, const void* a_dev, const void* wqkv_dev,
                      const float* bias_dev, void* q_out, void* k_out, void* vt_out, int B, int T,
                      void* stream);
+/* The same with the score domain made explicit: log2_domain = 1 folds log2(e) into the q scale as well (one rounding
+ * to the operand dtype), which is the q esmk_op_attention / esmk_op_attention_probs expect — the two ops then compose
+ * without a conversion; log2_domain = 0 is esmk_op_qkv_rope (q scaled by d^-1/2 only, the reference's q). */
+int esmk_op_qkv_rope2(esmk_model* m, const void* a_dev, const void* wqkv_dev,
+                      const float* bias_dev, void* q_out, void* k_out, void* vt_out, int B, int T,
+                      int log2_domain, void* stream);
 
 /* softmax(q k^T + key_bias) v  (multihead_attention.py:357-394), flash style.
  * SCORE DOMAIN: q must carry log2(e) besides d^-1/2 (esmk_forward's QKV epilogue folds both into the q scale

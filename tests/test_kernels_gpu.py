@@ -197,6 +197,50 @@ def test_qkv_rope(ops, E, H, B, T, dt):
     assert (vt.float() - ref_vt).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_inline_asm_mfma_matches_the_builtin(dt):
+    """common.h's mma_keep_c hides a v_mfma inside inline asm with hand-counted wait states; this runs it
+    next to the builtin MFMA (VALU writes of C right before, a dependent MFMA right after) on every toolchain the
+    library is built with: bit-equal results, C intact."""
+    from esm_amd import _native as N
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randn(64, 8, device="cuda", generator=g).to(dt)
+    b = torch.randn(64, 8, device="cuda", generator=g).to(dt)
+    c = torch.randn(64, 16, device="cuda", generator=g)
+    out = torch.zeros(3, 64, 16, device="cuda")
+    for _ in range(3):
+        N.check(N.lib.esmk_debug_mma_selftest(N.ptr(a), N.ptr(b), N.ptr(c), N.ptr(out), N.dtype_code(dt), N.cur_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], out[1]), (out[0] - out[1]).abs().max().item()
+    assert torch.equal(out[2], 2 * c)
+    assert out[0].abs().max().item() > 0
+
+
+def test_qkv_rope_composes_with_attention_through_the_c_abi(ops):
+    """esmk_op_qkv_rope2(log2_domain=1) hands esmk_op_attention the q it expects (log2(e) folded into the q
+    scale); chained, the two public ops reproduce softmax(q k^T / sqrt(d)) v of the reference
+    (multihead_attention.py:256-261,354-394) — without the flag the softmax would run at the wrong temperature."""
+    E, H, B, T, dt = 256, 4, 2, 192, torch.float16
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.randn(B * T, E, device="cuda", generator=g).to(dt)
+    w = (torch.randn(3 * E, E, device="cuda", generator=g) * (2.0 / math.sqrt(E))).to(dt)
+    bias = 0.1 * torch.randn(3 * E, device="cuda", generator=g)
+    hnd = ops.QkvHandle(E, H, dt)
+    q, k, vt = hnd(a, w, bias, B, T, log2_domain=True)
+    ctx = ops.attention(q, k, vt)
+    y = a.float() @ w.float().t() + bias
+    yq, yk, yv = [t.reshape(B, T, H, 64).permute(0, 2, 1, 3) for t in y.split(E, dim=1)]
+    yq, yk = _rope_ref(yq * 64 ** -0.5, hnd.inv_freq), _rope_ref(yk, hnd.inv_freq)
+    want = torch.softmax(yq @ yk.transpose(-1, -2), dim=-1) @ yv  # [B,H,T,64]
+    want = want.permute(0, 2, 1, 3).reshape(B * T, E)
+    err = (ctx.float() - want).abs().max().item()
+    assert err < 4e-3 * want.abs().max().item(), err
+    # and the natural-domain q of esmk_op_qkv_rope is that q divided by log2(e), to fp16 rounding
+    q0, _, _ = hnd(a, w, bias, B, T)
+    assert (q.float() / 1.4426950408889634 - q0.float()).abs().max().item() < 2e-3 * q0.float().abs().max().item()
+
+
 def _attn_ref(q, k, v, key_bias):
     s = q.float() @ k.float().transpose(-1, -2)
     if key_bias is not None:

@@ -1,0 +1,90 @@
+"""Round-3 GPU checks: outputs at <pad> positions, the per-call choice between the two persistent GEMM
+kernels, and the extraction writer's chunked jobs on the real device path."""
+import os
+
+import pytest
+import torch
+
+import esm
+from esm_amd.synth import synth_esm2_state_dict, synth_tokens
+
+pytestmark = pytest.mark.gpu
+
+
+def _small(L=3, E=128, H=2, seed=2):
+    m = esm.ESM2(L, E, H).eval()
+    m.load_state_dict(synth_esm2_state_dict(L, E, H, seed=seed))
+    return m.cuda()
+
+
+def test_pad_positions_are_finite_and_an_all_pad_sequence_gives_zeros_not_nan():
+    """Outputs at <pad> positions are UNSPECIFIED (README / INTEGRATION.md): the reference computes garbage there and
+    NaN for a sequence made of padding only; the engine copies the last real query row inside a wave, writes zeros for
+    padding-only waves — and never inf / NaN, because ESM_AMD_CHECK_FINITE and downstream reductions look at the whole
+    tensor.  Real rows are unaffected by their neighbours' padding: bit-equal to the sequence alone."""
+    model = _small()
+    T = 70
+    toks = synth_tokens(3, T - 2, seed=9)
+    toks[1, 21] = 2      # <eos> after 20 residues, padding behind it
+    toks[1, 22:] = 1
+    toks[2, :] = 1       # a sequence of padding only
+    with torch.no_grad():
+        out = model(toks.cuda(), repr_layers=[0, 3], need_head_weights=True)
+        alone = model(toks[:1].cuda(), repr_layers=[3])
+        short = model(toks[1:2, :22].cuda(), repr_layers=[3])
+    for name in ("logits", "attentions"):
+        assert torch.isfinite(out[name]).all(), name
+    for l in (0, 3):
+        assert torch.isfinite(out["representations"][l]).all(), l
+    assert torch.equal(out["representations"][3][0], alone["representations"][3][0])
+    assert torch.equal(out["representations"][3][1, :22], short["representations"][3][0])
+    # the all-pad sequence: no attention work at all (zeros), where the reference has NaN
+    assert out["attentions"][2].abs().max().item() == 0.0
+
+
+def test_gemm_kernel_choice_never_changes_a_bit(monkeypatch):
+    """gemm8 (two waves per SIMD) and gemm9 (one wave per SIMD) are interchangeable per call: the same forward with
+    every dense GEMM on gemm8, on gemm9, and with the library's own per-call choice gives identical tensors."""
+    from esm_amd import _native as N
+
+    L, E, H = 2, 1280, 20   # real layer shapes: 256 x 256 tiles in every GEMM
+    model = _small(L, E, H, seed=4)
+    toks = synth_tokens(64, 1022, seed=3).cuda()   # 65536 rows: the automatic choice takes gemm9 for q/k, v and fc2
+    outs = []
+    try:
+        for impl in (8, 9, 0):
+            N.check(N.lib.esmk_debug_gemm_impl(impl, 0))
+            with torch.no_grad():
+                o = model(toks, repr_layers=[L])
+            outs.append((o["representations"][L].clone(), o["logits"].clone()))
+    finally:
+        N.check(N.lib.esmk_debug_gemm_impl(0, 0))
+    for r, lg in outs[1:]:
+        assert torch.equal(r, outs[0][0]) and torch.equal(lg, outs[0][1])
+
+
+def test_extract_writes_every_sequence_once_with_chunked_writer_jobs(tmp_path):
+    """The device path of esm_amd.extract (pinned copies on a side stream, chunk jobs on the writer threads): every
+    sequence's file exists exactly once and holds the rows of a plain forward."""
+    from esm_amd.extract import extract, make_embed_fn
+
+    model = _small(3, 128, 2)
+    alphabet = esm.Alphabet.from_architecture("ESM-1b")
+    g = torch.Generator().manual_seed(1)
+    aas = "LAGVSERTIDPKQNFYMHWC"
+    seqs = ["".join(aas[i] for i in torch.randint(0, 20, (int(n),), generator=g).tolist())
+            for n in torch.randint(20, 90, (70,), generator=g)]
+    ds = esm.FastaBatchedDataset([f"p{i}" for i in range(len(seqs))], seqs)
+    means = extract(ds, alphabet, make_embed_fn(model, varlen=False), model.num_layers, model.embed_dim, [-1],
+                    ["mean", "per_tok"], output_dir=tmp_path, toks_per_batch=512, device=torch.device("cuda", 0),
+                    log=lambda s: None, writer_threads=4, chunk_rows=2)
+    files = sorted(p.name for p in tmp_path.glob("*.pt"))
+    assert files == sorted(f"p{i}.pt" for i in range(len(seqs)))
+    for i in (0, 17, 69):
+        r = torch.load(tmp_path / f"p{i}.pt")
+        toks = torch.tensor([[0] + alphabet.encode(seqs[i]) + [2]])
+        with torch.no_grad():
+            want = model(toks.cuda(), repr_layers=[3])["representations"][3][0, 1:-1].cpu()
+        assert torch.equal(r["representations"][3], want), i
+        assert torch.allclose(r["mean_representations"][3], want.mean(0), atol=1e-5)
+        assert torch.allclose(means[3][i].cpu(), want.mean(0), atol=1e-5)
