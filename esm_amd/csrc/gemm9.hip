@@ -9,8 +9,8 @@
 //   * fragment reads per MFMA drop by a third (32 KiB per 64 MFMAs per wave);
 //   * the wave's own instruction stream interleaves its 64 MFMAs with 32 ds_read_b128 and 16 LDS-DMA pieces, every
 //     MFMA gap carrying at most one read and one piece (pinned with sched_barrier: hipcc's own interleave bunches them);
-//   * TWO barriers per K tile, the LDS-DMA queue is never drained (counted vmcnt), a piece has 53 - 84 MFMA slots
-//     (~1 K tile) to land.
+//   * TWO barriers per K tile, the LDS-DMA queue is never drained (counted vmcnt), a piece has 62 - 92 MFMA slots
+//     (> 1 K tile) to land.
 // Every output element sees the same MFMA sequence over K as in gemm8 (bias enters as the C operand of the first
 // MFMA, then K ascending), so results are bit-identical to gemm8's (tools/bench_gemm9.py checks it on ragged shapes).
 //
@@ -33,11 +33,11 @@
 // One K tile (stream position s, LDS buffer cur = s & 1), MFMA slots m = 0..63 (m = 32 half + 16 ks + 4 j + i;
 // X = fragments of K 0..31, Y = fragments of K 32..63 of the tile):
 //     m  0..15   ds_read: Y fragments of position s (buffer cur) — X of position s was read during position s-1
-//     m 18       s_waitcnt lgkmcnt(0); s_barrier        every wave has read buffer cur completely
-//     m 18..48   LDS-DMA: the 16 pieces of position s+2 -> buffer cur, one every other slot
-//     m 46       s_waitcnt vmcnt(14); s_barrier         every wave's pieces of position s+1 have landed (the 14
+//     m 24       s_waitcnt lgkmcnt(0); s_barrier        every wave has read buffer cur completely
+//     m 24..54   LDS-DMA: the 16 pieces of position s+2 -> buffer cur, one every other slot
+//     m 52       s_waitcnt vmcnt(14); s_barrier         every wave's pieces of position s+1 have landed (the 14
 //                                                       youngest pieces, of position s+2, stay in flight)
-//     m 46..61   ds_read: X fragments of position s+1 (buffer cur^1)
+//     m 52..59   ds_read: X fragments of position s+1 (buffer cur^1), two per slot
 // The K tiles of all tiles of a workgroup form one stream, as in gemm8: the first operands of the next tile land
 // during the epilogue.
 #include "gemm_epi.h"
@@ -257,10 +257,18 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     constexpr bool NO_MFMA = (VAR & 16) != 0, NO_DMA = (VAR & 32) != 0, NO_RD = (VAR & 64) != 0, NO_EPI = (VAR & 128) != 0;
     // slots of the two barriers (VAR & 3: placement experiments; VAR & 8: without the s_barrier, results wrong)
     // measured (profiles/r3_gemm9_schedC_variants.log): 18/46 beats 20/40, 16/36 and 24/44 on all four layer shapes
-    constexpr int M_B1 = (VAR & 3) == 1 ? 16 : (VAR & 3) == 2 ? 24 : (VAR & 3) == 3 ? 20 : 18;
-    constexpr int M_B2 = (VAR & 3) == 1 ? 36 : (VAR & 3) == 2 ? 52 : (VAR & 3) == 3 ? 40 : 46;
+    // VAR & 3: 1 = one piece per slot instead of every other slot, 2 = 18/46, 3 = 20/40;
+    // VAR & 4: odd waves issue their pieces one slot later than even waves (half the TA burst).  Measured
+    // (profiles/r3_gemm9_schedC_variants*.log): 24/52 >= 18/46 > 20/40 > 16/36 on all four layer shapes, the dense
+    // issue -6 %, the stagger +-0; without the two barriers (wrong results) the kernel gains ~5 % — the chip then sits
+    // on the 1400 W cap at 1.4 - 1.5 GHz, where every variant of either kernel converges to 1.1 - 1.2 PFLOP/s.
+    constexpr int M_B1 = (VAR & 3) == 2 ? 18 : (VAR & 3) == 3 ? 20 : 24;
+    constexpr int M_B2 = (VAR & 3) == 2 ? 46 : (VAR & 3) == 3 ? 40 : 52;
+    constexpr int ISSUE_STEP = (VAR & 3) == 1 ? 1 : 2;
+    constexpr bool STAGGER = (VAR & 4) != 0;
     constexpr bool NO_BAR = (VAR & 8) != 0;
-    constexpr int IN_FLIGHT = (M_B2 - M_B1 + 1) / 2 > 16 ? 16 : (M_B2 - M_B1 + 1) / 2;  // pieces of position s+2 issued before the second barrier
+    // pieces of position s+2 issued before the second barrier
+    constexpr int IN_FLIGHT = (M_B2 - M_B1 + ISSUE_STEP - 1) / ISSUE_STEP > 16 ? 16 : (M_B2 - M_B1 + ISSUE_STEP - 1) / ISSUE_STEP;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -439,7 +447,15 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
             if (m < 32) mma1(xa, xw, m, first);
             else mma1(ya, yw, m, first);
             if (m < 16) rd1(ya, yw, sb, 1, m);
-            if (m >= M_B1 && m < M_B1 + 32 && ((m - M_B1) & 1) == 0) issue1((m - M_B1) >> 1, cur);
+            if constexpr (STAGGER) {  // (ISSUE_STEP == 2) even waves: slots M_B1, M_B1 + 2, ...; odd waves: one slot later
+                if (m >= M_B1 && m < M_B1 + 32 && ((m - M_B1) & 1) == 0) {
+                    if (!(wave & 1)) issue1((m - M_B1) >> 1, cur);
+                } else if (m > M_B1 && m < M_B1 + 33 && ((m - M_B1) & 1) == 1) {
+                    if (wave & 1) issue1((m - M_B1 - 1) >> 1, cur);
+                }
+            } else if (m >= M_B1 && m < M_B1 + 16 * ISSUE_STEP && ((m - M_B1) % ISSUE_STEP) == 0) {
+                issue1((m - M_B1) / ISSUE_STEP, cur);
+            }
             if constexpr (M_B2 + 16 <= 64) {
                 if (m >= M_B2 && m < M_B2 + 16) rd1(xa, xw, sn, 0, m - M_B2);
             } else {  // late second barrier: two reads per slot
@@ -595,6 +611,8 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
                 case 1: return launch9<T, EPI_STORE_T, 1>(p, st);
                 case 2: return launch9<T, EPI_STORE_T, 2>(p, st);
                 case 3: return launch9<T, EPI_STORE_T, 3>(p, st);
+                case 4: return launch9<T, EPI_STORE_T, 4>(p, st);
+                case 5: return launch9<T, EPI_STORE_T, 5>(p, st);
                 case 8: return launch9<T, EPI_STORE_T, 8>(p, st);
                 case 16: return launch9<T, EPI_STORE_T, 16>(p, st);
                 case 32: return launch9<T, EPI_STORE_T, 32>(p, st);

@@ -130,7 +130,7 @@ def main():
         flops = 2.0 * M * N * K
         arms = [("gemm8", 8, 0), ("gemm9", 9, 0)]
         if args.dbg and epi == nat.EPI_STORE_T:
-            arms += [("g9 b16/36", 9, 1), ("g9 b24/44", 9, 2), ("g9 b18/46", 9, 3), ("g9 no-barrier", 9, 8), ("g9 no-mfma", 9, 16), ("g9 no-dma", 9, 32), ("g9 no-reads", 9, 64), ("g9 no-epi", 9, 128),
+            arms += [("g9 dense-issue", 9, 1), ("g9 stagger", 9, 4), ("g9 b24/52", 9, 2), ("g9 no-barrier", 9, 8), ("g9 no-mfma", 9, 16), ("g9 no-dma", 9, 32), ("g9 no-reads", 9, 64), ("g9 no-epi", 9, 128),
                      ("g9 mfma-only", 9, 96), ("g9 skeleton", 9, 224)]
         times = {n: [] for n, _, _ in arms}
         if not args.no_vendor and epi == nat.EPI_STORE_T:

@@ -79,9 +79,13 @@ def main():
             flops = 2.0 * M * N * K
             fv = lambda: torch.nn.functional.linear(a, w, bias_t)
             fo = lambda: ops.linear(a, w, bias, nat.EPI_STORE_T, out=out)
+            nat.check(nat.lib.esmk_debug_gemm_impl(8, 0))
             msv, mso = timeit(fv, args.iters), timeit(fo, args.iters)
+            nat.check(nat.lib.esmk_debug_gemm_impl(9, 0))
+            ms9 = timeit(fo, args.iters)
+            nat.check(nat.lib.esmk_debug_gemm_impl(8, 0))
             line = (f"{str(dt)[6:]:9s} {name:11s} M={M} N={N:5d} K={K:5d}: vendor {msv*1e3:8.1f} us {flops/msv/1e9:7.1f} TF | "
-                    f"gemm8 {mso*1e3:8.1f} us {flops/mso/1e9:7.1f} TF")
+                    f"gemm8 {mso*1e3:8.1f} us {flops/mso/1e9:7.1f} TF | gemm9 {ms9*1e3:8.1f} us {flops/ms9/1e9:7.1f} TF")
             if args.zeros:
                 a.zero_()
                 w.zero_()
@@ -91,7 +95,8 @@ def main():
             if args.smi and name == "fc1" and dt == torch.float16:
                 a.copy_(rnd(M, K).to(dt))
                 w.copy_((rnd(N, K) / math.sqrt(K)).to(dt))
-                for label, fn in (("vendor", fv), ("gemm8", fo)):
+                for label, fn in (("vendor", fv), ("gemm8", fo), ("gemm9", fo)):
+                    nat.check(nat.lib.esmk_debug_gemm_impl(9 if label == "gemm9" else 8, 0))
                     s = Smi()
                     s.start()
                     t0 = time.time()
@@ -105,6 +110,7 @@ def main():
                     if tail:
                         print(f"    rocm-smi under {label} loop: sclk {sum(x[0] for x in tail)/len(tail):.0f} MHz, "
                               f"power {sum(x[1] for x in tail)/len(tail):.0f} W ({len(tail)} samples)", flush=True)
+            nat.check(nat.lib.esmk_debug_gemm_impl(0, 0))
             del a, w, out
 
 
