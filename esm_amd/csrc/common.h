@@ -32,6 +32,9 @@ struct Op<_Float16> {
         asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
         return d;
     }
+    // 16 x 16 x 32: D[i][j] += sum_k a[i][k] b[j][k];  lane l supplies a[l & 15][8 (l >> 4) .. + 8], b likewise, and
+    // holds D[4 (l >> 4) + r][l & 15], r = 0..3
+    static ESMK_DEV f32x4 mma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
     static ESMK_DEV _Float16 from(float x) { return (_Float16)x; }
     static ESMK_DEV float to(_Float16 x) { return (float)x; }
 };
@@ -48,6 +51,7 @@ struct Op<__bf16> {
         asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
         return d;
     }
+    static ESMK_DEV f32x4 mma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
     static ESMK_DEV __bf16 from(float x) { return (__bf16)x; }
     static ESMK_DEV float to(__bf16 x) { return (float)x; }
 };

@@ -27,236 +27,11 @@
 // Generic kernel (gemm64): 64x64 tile, K step 32, register staged with row clamping and
 // per-element predicated stores; used for shapes the fast kernel does not cover
 // (K % 64 != 0, N % 4 != 0 such as the 33-wide vocabulary projection).
-#include "common.h"
-#include "kernels.h"
+#include "gemm_epi.h"
 #include <stdlib.h>
 #include <string.h>
 
 namespace esmk {
-
-// --------------------------------------------------------------------------------------------
-// epilogue
-// --------------------------------------------------------------------------------------------
-// Every wave owns a [128 (m)] x [64 (n)] block of the output tile and, once the K loop is done,
-// a private 16 KiB slice of the (now idle) LDS.  The MFMA accumulator layout gives a lane 4
-// consecutive columns of 32 different rows, i.e. 8-byte pieces scattered over 32 cache lines per
-// store instruction; instead the block is first written to the LDS slice (XOR-swizzled 16-byte
-// chunks) and then drained row by row with 16 B per lane, so every global store instruction
-// covers whole 128 B / 256 B row segments (8 or 4 full rows per instruction).
-template <typename T>
-ESMK_DEV typename Op<T>::v4 pack4(float a, float b, float c, float d) {
-    typename Op<T>::v4 v;
-    v[0] = Op<T>::from(a);
-    v[1] = Op<T>::from(b);
-    v[2] = Op<T>::from(c);
-    v[3] = Op<T>::from(d);
-    return v;
-}
-
-// layout A: [128 rows][128 B]  (64 operand-dtype elements per row), chunk c in [0,8)
-ESMK_DEV int lds_a(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
-// layout B: [64 rows][256 B]   (64 fp32 or 128 operand-dtype elements per row), chunk c in [0,16)
-ESMK_DEV int lds_b(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
-
-// acc[j][i][r] in the "swapped" orientation (MFMA A operand = weight rows):
-//   m = m_base + 32 i + (lane & 31);  n = n_base + 32 j + 8 (r>>2) + 4 (lane>>5) + (r&3).
-// With vswap (V tiles of the fused QKV projection, MFMA A operand = activation rows):
-//   n = n_base + 32 j + (lane & 31);  m = m_base + 32 i + 8 (r>>2) + 4 (lane>>5) + (r&3).
-template <typename T, int EPI>
-ESMK_DEV void epilogue_wave(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int n_base,
-                            int lane, char* wl) {
-    using V4 = typename Op<T>::v4;
-    using V8 = typename Op<T>::v8;
-    const int h = lane >> 5, lm = lane & 31;
-    if (n_base >= p.N || m_base >= p.M) return;
-    if constexpr (EPI == EPI_V_T) {
-        // V projection, accumulated with exchanged MFMA operands: the lane owns output channel
-        // dv = 32 j + (lane & 31) and 4 consecutive tokens.  Result goes to vt[b][head][dv][Tp]
-        // with keys permuted inside groups of 16 (4-groups 1 and 2 swapped) so the attention kernel
-        // reads the 8 keys of one MFMA k-slot as 16 contiguous bytes.
-        const int head = n_base >> 6;
-        const bool aligned = (p.T % 128 == 0);  // the wave's 128 tokens = one aligned run of one sequence
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int dv = 32 * j + lm;
-            const float bv = p.bias[n_base + dv];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    // aligned: store in the permuted key order; otherwise in token order
-                    const int chunk = aligned ? 4 * i + 2 * (g >> 1) + h : 4 * i + g;
-                    const int half = aligned ? (g & 1) : h;
-                    *reinterpret_cast<V4*>(wl + lds_b(dv, chunk) + 8 * half) =
-                        pack4<T>(acc[j][i][4 * g] + bv, acc[j][i][4 * g + 1] + bv,
-                                 acc[j][i][4 * g + 2] + bv, acc[j][i][4 * g + 3] + bv);
-                }
-        }
-        T* vt = reinterpret_cast<T*>(p.vt);
-        if (aligned) {
-            const int b = m_base / p.T, t0 = m_base - b * p.T;
-            T* base = vt + ((size_t)(b * p.H + head) * 64) * p.Tp + t0;
-            V8 v[16];
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int pc = it * 64 + lane;
-                v[it] = *reinterpret_cast<const V8*>(wl + lds_b(pc >> 4, pc & 15));
-            }
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int pc = it * 64 + lane;
-                *reinterpret_cast<V8*>(base + (size_t)(pc >> 4) * p.Tp + (pc & 15) * 8) = v[it];
-            }
-        } else {
-            // any T: per-element stores with the key permutation applied per token
-#pragma unroll 1
-            for (int idx = lane; idx < 64 * 128; idx += 64) {
-                const int r = idx >> 7, tl = idx & 127;
-                const int m = m_base + tl;
-                if (m >= p.M) continue;
-                const T v = *reinterpret_cast<const T*>(wl + lds_b(r, tl >> 3) + 2 * (tl & 7));
-                const int b = m / p.T, t = m - b * p.T;
-                const int t16 = t & 15;
-                const int tp = (t & ~15) | ((((t16 >> 2) & 1) << 3) | (((t16 >> 3) & 1) << 2) | (t16 & 3));
-                vt[((size_t)(b * p.H + head) * 64 + r) * (size_t)p.Tp + tp] = v;
-            }
-        }
-    } else if constexpr (EPI == EPI_QKV_ROPE) {
-        // q and k projections (N = 2E): the wave's 64 columns are exactly one head (head_dim 64)
-        const int which = n_base / p.E;  // 0 q, 1 k   (wave uniform)
-        const int head = (n_base - which * p.E) >> 6;
-        // q / k: bias, q scaling (mha.py:261), rotation (rotary_embedding.py:11-20) -> LDS rows
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 32 * i + lm;
-            const int m = min(m_base + row, p.M - 1);
-            const int t = m % p.T;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = 8 * g + 4 * h;  // first of 4 consecutive dims in [0,32)
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n_base + d0);
-                const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.bias + n_base + 32 + d0);
-                const f32x4 c = *reinterpret_cast<const f32x4*>(p.cos + (size_t)t * 32 + d0);
-                const f32x4 s = *reinterpret_cast<const f32x4*>(p.sin + (size_t)t * 32 + d0);
-                float y1[4], y2[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float a1 = acc[0][i][4 * g + e] + b1[e];
-                    float a2 = acc[1][i][4 * g + e] + b2[e];
-                    if (which == 0) {
-                        a1 *= p.scaling;
-                        a2 *= p.scaling;
-                    }
-                    // x*cos + rotate_half(x)*sin, rotate_half(x) = cat(-x2, x1)
-                    y1[e] = a1 * c[e] - a2 * s[e];
-                    y2[e] = a2 * c[e] + a1 * s[e];
-                }
-                *reinterpret_cast<V4*>(wl + lds_a(row, g) + 8 * h) = pack4<T>(y1[0], y1[1], y1[2], y1[3]);
-                *reinterpret_cast<V4*>(wl + lds_a(row, 4 + g) + 8 * h) = pack4<T>(y2[0], y2[1], y2[2], y2[3]);
-            }
-        }
-        T* qk = reinterpret_cast<T*>(which == 0 ? p.q : p.k);
-        V8 v[16];
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int pc = it * 64 + lane;
-            v[it] = *reinterpret_cast<const V8*>(wl + lds_a(pc >> 3, pc & 7));
-        }
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int pc = it * 64 + lane;
-            const int m = m_base + (pc >> 3);
-            if (m < p.M) {
-                const int b = m / p.T, t = m - b * p.T;
-                *reinterpret_cast<V8*>(qk + ((size_t)(b * p.H + head) * p.T + t) * 64 + (pc & 7) * 8) = v[it];
-            }
-        }
-    } else if constexpr (EPI == EPI_STORE_T || EPI == EPI_GELU_T) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n_base + 32 * j + 8 * g + 4 * h;
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e] + bv[e];
-                    if constexpr (EPI == EPI_GELU_T) gelu_fast_x4(v);
-                    *reinterpret_cast<V4*>(wl + lds_a(32 * i + lm, 4 * j + g) + 8 * h) =
-                        pack4<T>(v[0], v[1], v[2], v[3]);
-                }
-            }
-        T* out = reinterpret_cast<T*>(p.out);
-        V8 v[16];  // all LDS reads first, then the stores (no per-row LDS round trip)
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int pc = it * 64 + lane;
-            v[it] = *reinterpret_cast<const V8*>(wl + lds_a(pc >> 3, pc & 7));
-        }
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int pc = it * 64 + lane;
-            const int m = m_base + (pc >> 3), n = n_base + (pc & 7) * 8;
-            if (m < p.M && n < p.N) *reinterpret_cast<V8*>(out + (size_t)m * p.N + n) = v[it];
-        }
-    } else {
-        // fp32 outputs: two passes of 64 rows x 256 B
-        float* out = reinterpret_cast<float*>(p.out);
-#pragma unroll
-        for (int hp = 0; hp < 2; ++hp) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = n_base + 32 * j + 8 * g + 4 * h;
-                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                    if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-                    for (int ii = 0; ii < 2; ++ii) {
-                        const int i = 2 * hp + ii;
-                        f32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e] + bv[e];
-                        if constexpr (EPI == EPI_GELU_F32) gelu_fast_x4(v);
-                        *reinterpret_cast<f32x4*>(wl + lds_b(32 * ii + lm, 8 * j + 2 * g + h)) = v;
-                    }
-                }
-            // 2 x 8 row groups: all LDS reads and all residual loads are issued before the first
-            // dependent add / store (tail rows and columns are clamped for the load, predicated
-            // for the store)
-#pragma unroll
-            for (int q8 = 0; q8 < 2; ++q8) {
-                f32x4 v[8], old[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int pc = (8 * q8 + u) * 64 + lane;
-                    v[u] = *reinterpret_cast<const f32x4*>(wl + lds_b(pc >> 4, pc & 15));
-                }
-                if constexpr (EPI == EPI_RESID_F32) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int pc = (8 * q8 + u) * 64 + lane;
-                        const int m = min(m_base + 64 * hp + (pc >> 4), p.M - 1);
-                        const int n = min(n_base + (pc & 15) * 4, p.N - 4);
-                        old[u] = *reinterpret_cast<const f32x4*>(out + (size_t)m * p.N + n);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int pc = (8 * q8 + u) * 64 + lane;
-                    const int m = m_base + 64 * hp + (pc >> 4), n = n_base + (pc & 15) * 4;
-                    f32x4 r = v[u];
-                    if constexpr (EPI == EPI_RESID_F32)
-                        r = f32x4{old[u][0] + r[0], old[u][1] + r[1], old[u][2] + r[2], old[u][3] + r[3]};
-                    if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(out + (size_t)m * p.N + n) = r;
-                }
-            }
-        }
-    }
-}
 
 // --------------------------------------------------------------------------------------------
 // fast kernel: 256 x 256 x 64
@@ -312,42 +87,54 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) stage_part(buf, kt, j);
     };
 
-    // fragment read offsets (bytes) inside a tile
-    const int lrow = (lane & 31) * 128;
+    // fragment read offsets (bytes) inside a tile: 16 x 16 x 32 MFMA blocks, lane l reads row l & 15 of a 16-row
+    // block and 16-byte chunk 4 kh + (l >> 4) of its 128-byte row (kh = K half of the tile)
+    const int lrow = (lane & 15) * 128;
     const int swz = (lane >> 1) & 7;
-    int xo[4];
+    int xo[2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) xo[ks] = ((2 * ks + (lane >> 5)) ^ swz) << 4;
+    for (int ks = 0; ks < 2; ++ks) xo[ks] = ((4 * ks + (lane >> 4)) ^ swz) << 4;
     const int a_off = (wm * 128) * 128 + lrow;                // activation rows of this wave
     const int w_off = G_TILE_BYTES + (wn * 64) * 128 + lrow;  // weight rows of this wave
 
-    f32x16 acc[2][4];
+    // acc = bias (gemm8's order: the bias rides through the K loop), EPI_V_T adds it in its epilogue
+    f32x4 acc[4][8];  // [16-column block][16-row block]
+    {
+        const int nb = n0 + wn * 64;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int r = 0; r < 4; ++r) {
+                const int n = nb + 16 * nj + 4 * (lane >> 4) + r;
+                const float b = (EPI != EPI_V_T && p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+                for (int mi = 0; mi < 8; ++mi) acc[nj][mi][r] = b;
+            }
+    }
 
     using V8 = typename Op<T>::v8;
-    struct Frags {
-        V8 w[2], a[4];
+    struct Frags {  // one K half: 4 column blocks, 4 of the 8 row blocks (hm = 0: rows 0..63, 1: rows 64..127)
+        V8 w[4], a[4];
     };
+    // step ks = 0..3: K half ks >> 1, row blocks 4 (ks & 1) .. + 3
     auto read_frags = [&](Frags& f, const char* sb, int ks) {
+        const int kh = ks >> 1, hm = ks & 1;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) f.w[j] = *reinterpret_cast<const V8*>(sb + w_off + j * 4096 + xo[ks]);
+        for (int j = 0; j < 4; ++j) f.w[j] = *reinterpret_cast<const V8*>(sb + w_off + j * 2048 + xo[kh]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f.a[i] = *reinterpret_cast<const V8*>(sb + a_off + i * 4096 + xo[ks]);
+        for (int i = 0; i < 4; ++i) f.a[i] = *reinterpret_cast<const V8*>(sb + a_off + (4 * hm + i) * 2048 + xo[kh]);
     };
-    auto mma8 = [&](const Frags& f) {
+    auto mma8 = [&](const Frags& f, int ks) {
+        const int hm = ks & 1;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                f32x4& c = acc[j][4 * hm + i];
                 if constexpr (EPI == EPI_V_T)  // lane owns 4 consecutive tokens of one channel
-                    acc[j][i] = Op<T>::mma(f.a[i], f.w[j], acc[j][i]);
+                    c = Op<T>::mma16(f.a[i], f.w[j], c);
                 else  // lane owns 4 consecutive channels of one token
-                    acc[j][i] = Op<T>::mma(f.w[j], f.a[i], acc[j][i]);
+                    c = Op<T>::mma16(f.w[j], f.a[i], c);
             }
     };
 
@@ -366,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     // (lgkmcnt) in front of it, i.e. BEFORE the next slice's reads are issued, when only the needed
     // reads are outstanding (it otherwise waits for the just-issued prefetch as well).
     auto arrived = [&](Frags& f) {
-        asm volatile("" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]));
+        asm volatile("" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3]), "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]));
         __builtin_amdgcn_sched_barrier(0);
     };
     for (int kt = 0; kt < nk; ++kt) {
@@ -393,10 +180,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
             continue;
         }
         if constexpr (DBG & 4) {  // timing experiment: MFMA only
-            mma8(f0);
-            mma8(f0);
-            mma8(f0);
-            mma8(f0);
+            mma8(f0, 0);
+            mma8(f0, 1);
+            mma8(f0, 2);
+            mma8(f0, 3);
             if constexpr (!(DBG & 2)) __syncthreads();
             continue;
         }
@@ -404,19 +191,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         read_frags(f1, sb, 1);
         stage_some(0, C0);
         __builtin_amdgcn_sched_barrier(0);
-        mma8(f0);
+        mma8(f0, 0);
         __builtin_amdgcn_sched_barrier(0);
         arrived(f1);
         read_frags(f0, sb, 2);
         stage_some(C0, C1);
         __builtin_amdgcn_sched_barrier(0);
-        mma8(f1);
+        mma8(f1, 1);
         __builtin_amdgcn_sched_barrier(0);
         arrived(f0);
         read_frags(f1, sb, 3);
         stage_some(C0 + C1, C2);
         __builtin_amdgcn_sched_barrier(0);
-        mma8(f0);
+        mma8(f0, 2);
         __builtin_amdgcn_sched_barrier(0);
         arrived(f1);
         stage_some(C0 + C1 + C2, C3);
@@ -426,12 +213,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         }
         read_frags(f0, smem + (cur ^ 1) * G_STAGE_BYTES, 0);  // (harmless stale read after the last tile)
         __builtin_amdgcn_sched_barrier(0);
-        mma8(f1);
+        mma8(f1, 3);
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();  // all MFMA operands consumed before the LDS is reused by the epilogue
 
-    epilogue_wave<T, EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * 16384);
+    epilogue8m<T, EPI, false>(p, acc, 0, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * 16384, 0, 0, 0);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -567,7 +354,7 @@ static hipError_t dispatch(const GemmArgs& p, int epi, hipStream_t st) {
 // are gemm8's: their gain in the loop is lost in the single-wave epilogue), gemm8 otherwise.  Both give the same bits.
 // ESMK_GEMM_IMPL = 8 | 9 | 9:<variant> | auto;  ESMK_GEMM9_MASK = bit mask over epilogue codes for auto,
 // ESMK_GEMM9_MIN_K = shortest K of the residual GEMM that goes to gemm9 (default 2560).
-static int g_impl = -1, g_impl_var = 0, g_mask9 = (1 << EPI_RESID_F32) | (1 << EPI_QKV_ROPE) | (1 << EPI_V_T), g_mink9 = 2560;
+static int g_impl = -1, g_impl_var = 0, g_mask9 = 127, g_mink9 = 0, g_auto_var = 0;
 void gemm_set_impl(int impl, int var) {
     g_impl = impl;
     g_impl_var = var;
@@ -581,17 +368,18 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
         g_impl_var = (e != nullptr && e[0] == '9' && e[1] == ':') ? atoi(e + 2) : 0;
         if (const char* m = getenv("ESMK_GEMM9_MASK")) g_mask9 = atoi(m);
         if (const char* k = getenv("ESMK_GEMM9_MIN_K")) g_mink9 = atoi(k);
+        if (const char* v = getenv("ESMK_GEMM9_VAR")) g_auto_var = atoi(v);  // issue pattern of the auto choice (2 | 3: A/B)
     }
     static const bool env_old = [] {
         const char* e = getenv("ESMK_GEMM");
         return e != nullptr && strcmp(e, "old") == 0;
     }();
     if (!env_old && !p.force_old && !p.force_generic && !p.dbg && g_impl != 8 && gemm9_supports(p, epi)) {
-        if (g_impl == 9) return launch_gemm9(p, epi, operand_dtype, g_impl_var, st);
+        if (g_impl == 9 && g_impl_var >= 0) return launch_gemm9(p, epi, operand_dtype, g_impl_var, st);
         // auto: only launches that fill the chip for at least one round (small batches keep gemm8's half-height tiles)
         const long long tiles = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         if (((g_mask9 >> epi) & 1) && (epi != EPI_RESID_F32 || p.K >= g_mink9) && tiles >= 256)
-            return launch_gemm9(p, epi, operand_dtype, 0, st);
+            return launch_gemm9(p, epi, operand_dtype, g_auto_var, st);
     }
     if (!env_old && !p.force_old && !p.force_generic && gemm8_supports(p, epi))
         return launch_gemm8(p, epi, operand_dtype, st);

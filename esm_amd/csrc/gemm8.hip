@@ -214,55 +214,61 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
         for (int k = 0; k < PF; ++k) advance_pf();
     }
 
-    // ---- fragment read offsets -----------------------------------------------------------------
-    const int lrow = (lane & 31) * 128;
+    // ---- fragment read offsets (16 x 16 x 32 MFMA blocks: lane l reads row l & 15 of a 16-row block, 16-byte chunk
+    // 4 ks + (l >> 4) of its 128-byte row; ks = K half of the tile) ----------------------------------------------
+    const int lrow = (lane & 15) * 128;
     const int swz = (lane >> 1) & 7;
-    int xo[4];
+    int xo[2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) xo[ks] = ((2 * ks + (lane >> 5)) ^ swz) << 4;
+    for (int ks = 0; ks < 2; ++ks) xo[ks] = ((4 * ks + (lane >> 4)) ^ swz) << 4;
     const int a_off = grp * (64 * 128) + lrow;
     const int w_off = wn * (32 * 128) + lrow;
 
-    V8 fa[2][4], fb[2][4], fw0[4], fw1[4];  // fb: (i2,i3) fragments, SCHED 1 only
-    f32x16 acc[2][4];
+    V8 fa[4][2], fb[4][2], fw0[2][2], fw1[2][2];  // [16-row / 16-column block][K half]; fb: rows 64..127, SCHED 1 only
+    f32x4 acc[4][8];                              // [16-column block of the wave's 64][16-row block of its 128]
     if constexpr (DBG & 4) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                fa[0][ks][e] = fa[1][ks][e] = fb[0][ks][e] = fb[1][ks][e] = Op<T>::from(0.f);
-                fw0[ks][e] = fw1[ks][e] = Op<T>::from(0.f);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) fa[b][ks][e] = fb[b][ks][e] = Op<T>::from(0.f);
+                fw0[0][ks][e] = fw0[1][ks][e] = fw1[0][ks][e] = fw1[1][ks][e] = Op<T>::from(0.f);
             }
     }
 
-    auto rdA = [&](V8 (&f)[2][4], const char* ub) {
+    auto rdA = [&](V8 (&f)[4][2], const char* ub) {
         if constexpr (DBG & 4) return;
 #pragma unroll
-        for (int i2 = 0; i2 < 2; ++i2)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                f[i2][ks] = *reinterpret_cast<const V8*>(ub + a_off + i2 * 4096 + xo[ks]);
+            for (int ks = 0; ks < 2; ++ks) f[b][ks] = *reinterpret_cast<const V8*>(ub + a_off + b * 2048 + xo[ks]);
     };
-    auto rdW = [&](V8 (&fw)[4], const char* ub) {
+    auto rdW = [&](V8 (&fw)[2][2], const char* ub) {
         if constexpr (DBG & 4) return;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fw[ks] = *reinterpret_cast<const V8*>(ub + w_off + xo[ks]);
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fw[b][ks] = *reinterpret_cast<const V8*>(ub + w_off + b * 2048 + xo[ks]);
     };
-    // one 64 x 32 quadrant over K = 64: 8 MFMAs, the two accumulators alternate
-    auto quad = [&](f32x16& c0, f32x16& c1, const V8 (&fw)[4], const V8 (&f)[2][4]) {
+    // one 64 x 32 quadrant over K = 64: 16 MFMAs on 8 accumulators (column blocks 2 jb, 2 jb + 1; row blocks 4 ib ..)
+    auto quad = [&](int jb, int ib, const V8 (&fw)[2][2], const V8 (&f)[4][2]) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if constexpr (DBG & 1) {
-                asm volatile("" ::"v"(fw[ks]), "v"(f[0][ks]), "v"(f[1][ks]));
-            } else if constexpr (EPI == EPI_V_T) {  // lane owns 4 consecutive tokens of one channel
-                c0 = Op<T>::mma(f[0][ks], fw[ks], c0);
-                c1 = Op<T>::mma(f[1][ks], fw[ks], c1);
-            } else {  // lane owns 4 consecutive channels of one token
-                c0 = Op<T>::mma(fw[ks], f[0][ks], c0);
-                c1 = Op<T>::mma(fw[ks], f[1][ks], c1);
-            }
-        }
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    f32x4& c = acc[2 * jb + nb][4 * ib + mb];
+                    if constexpr (DBG & 1) {
+                        asm volatile("" ::"v"(fw[nb][ks]), "v"(f[mb][ks]));
+                    } else if constexpr (EPI == EPI_V_T) {  // lane owns 4 consecutive tokens of one channel
+                        c = Op<T>::mma16(f[mb][ks], fw[nb][ks], c);
+                    } else {  // lane owns 4 consecutive channels of one token
+                        c = Op<T>::mma16(fw[nb][ks], f[mb][ks], c);
+                    }
+                }
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -275,46 +281,46 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
         bool done = false;
         if constexpr (EPI != EPI_V_T) {
             if (p.bias != nullptr) {
-                const int hsel = lane >> 5;
+                const int g4 = lane >> 4;  // the lane's columns of a 16-column block: 4 g4 .. 4 g4 + 3
                 if (n_base + 64 <= p.N) {
-                    cfloat_ptr cb = (cfloat_ptr)(unsigned long long)(p.bias + n_base);
+                    typedef const __attribute__((address_space(4))) f32x16* cvec_ptr;
+                    cvec_ptr cb = (cvec_ptr)(unsigned long long)(p.bias + n_base);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int nj = 0; nj < 4; ++nj) {
+                        // 16 SGPRs at a time (the whole row would pin 64 SGPRs next to the loop state): one s_load_dwordx16
+                        const f32x16 bb = cb[nj];
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            // 8 SGPRs at a time (the whole row would pin 64 SGPRs next to the loop state)
+                        for (int r = 0; r < 4; ++r) {
+                            // two-level select on the bits of g4 over OPAQUE scalars (hipcc folds a visible select chain
+                            // into a dynamic vector index — 15 selects per value — or into per-lane global loads)
+                            float e0 = bb[r], e1 = bb[4 + r], e2 = bb[8 + r], e3 = bb[12 + r];
+                            asm volatile("" : "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3));
+                            const float lo = (lane & 16) ? e1 : e0, hi = (lane & 16) ? e3 : e2;
+                            const float b = (lane & 32) ? hi : lo;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float b0 = cb[32 * j + 8 * g + e], b1 = cb[32 * j + 8 * g + 4 + e];
-                                const float b = hsel ? b1 : b0;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) acc[j][i][4 * g + e] = b;
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
+                            for (int mi = 0; mi < 8; ++mi) acc[nj][mi][r] = b;
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 } else {  // N tail: clamped vector loads
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = n_base + 16 * nj + 4 * g4 + r;
+                            const float b = n < p.N ? p.bias[n] : 0.f;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int n = n_base + 32 * j + 8 * g + 4 * hsel + e;
-                                const float b = n < p.N ? p.bias[n] : 0.f;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) acc[j][i][4 * g + e] = b;
-                            }
+                            for (int mi = 0; mi < 8; ++mi) acc[nj][mi][r] = b;
+                        }
                 }
                 done = true;
             }
         }
         if (!done) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+                for (int mi = 0; mi < 8; ++mi) acc[nj][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
 
@@ -361,20 +367,20 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
             issue(sW1, 2, cur ^ 1);
             wait_units();
             wg_barrier();
-            quad(acc[0][0], acc[0][1], fw0, fa);
+            quad(0, 0, fw0, fa);
             wg_barrier();
             // ---- phase 1 -----------------------------------------------------------------------
             rdW(fw1, sb + 2 * P_UNIT);
             issue(sA1, 3, cur ^ 1);
             wait_units();
             wg_barrier();
-            quad(acc[1][0], acc[1][1], fw1, fa);
+            quad(1, 0, fw1, fa);
             wg_barrier();
             // ---- phase 2 -----------------------------------------------------------------------
             if constexpr (!HM) rdA(fa, sb + 3 * P_UNIT);
             issue(sA0, 0, cur);
             wg_barrier();
-            if constexpr (!HM) quad(acc[1][2], acc[1][3], fw1, fa);
+            if constexpr (!HM) quad(1, 1, fw1, fa);
             wg_barrier();
             // ---- phase 3 -----------------------------------------------------------------------
             issue(sW0, 1, cur);
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
             if constexpr (XPF)
                 if (last_kt) prefetch_x();  // after the K tile's last counted wait (last_kt: the K tile chosen for it)
             wg_barrier();
-            if constexpr (!HM) quad(acc[0][2], acc[0][3], fw0, fa);
+            if constexpr (!HM) quad(0, 1, fw0, fa);
             wg_barrier();
         } else {
             // fa = (i0,i1) fragments of this position, read in L3 of the previous position
@@ -392,25 +398,25 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
             issue(sW1, 2, cur ^ 1);
             wait_units();  // U2 of cur
             wg_barrier();
-            quad(acc[0][0], acc[0][1], fw0, fa);
+            quad(0, 0, fw0, fa);
             wg_barrier();
             rdW(fw1, sb + 2 * P_UNIT);
             issue(sA1, 3, cur ^ 1);
             wait_units();  // U3 of cur
             wg_barrier();
-            quad(acc[1][0], acc[1][1], fw1, fa);
+            quad(1, 0, fw1, fa);
             wg_barrier();
             rdA(fb, sb + 3 * P_UNIT);
             issue(sA0, 0, cur);
             wait_units();  // U0 of cur^1 (next position)
             wg_barrier();
-            quad(acc[1][2], acc[1][3], fw1, fb);
+            quad(1, 1, fw1, fb);
             wg_barrier();
             rdA(fa, smem + (cur ^ 1) * P_BUF);
             issue(sW0, 1, cur);
             wait_units();  // U1 of cur^1
             wg_barrier();
-            quad(acc[0][2], acc[0][3], fw0, fb);
+            quad(0, 1, fw0, fb);
             wg_barrier();
         }
         cur ^= 1;
@@ -451,15 +457,15 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
         char* slice = smem + P_EPI + wave * P_SLICE;
         if constexpr (DBG & 8) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[j][i]));
+                for (int mi = 0; mi < 8; ++mi) asm volatile("" ::"v"(acc[nj][mi]));
         } else {
             bool full = (m_base + GM <= p.M) && (n_base + 64 <= p.N);
             if constexpr (EPI == EPI_V_T) full = full && (p.T % 32 == 0);
             constexpr int NI = HM ? 2 : 4;
-            if (full) epilogue8<T, EPI, true, (DBG & 16) != 0, GEN, NI>(p, acc, m_base, n_base, lane, slice, out_off, zo, zi);
-            else epilogue8<T, EPI, false, (DBG & 16) != 0, GEN, NI>(p, acc, m_base, n_base, lane, slice, out_off, zo, zi);
+            if (full) epilogue8m<T, EPI, true, (DBG & 16) != 0, GEN, NI>(p, acc, 0, m_base, n_base, lane, slice, out_off, zo, zi);
+            else epilogue8m<T, EPI, false, (DBG & 16) != 0, GEN, NI>(p, acc, 0, m_base, n_base, lane, slice, out_off, zo, zi);
             young_stores = full && !(DBG & 16) && !HM;
         }
         if constexpr (XPF) asm volatile("" : "+v"(x_dummy));  // the epilogue's own loads retired them

@@ -59,17 +59,17 @@ constexpr int Q_LDS = Q_EPI + 4 * Q_SLICE;   // 160 KiB
 // Epilogues of the wave's 128 x 128 block.  The accumulators live in AGPRs; ds_write_b128 takes them from there, so
 // every epilogue writes fp32 quads straight into the wave's LDS slice and does its arithmetic on the transposed
 // (row-major) read — no v_accvgpr_read pass, few live VGPRs.
-// acc[hf][j2][i][r]:  m = m_base + 32 i + (lane & 31);  n = n_base + 64 hf + 32 j2 + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)
+// acc[nj][mi][r] (16 x 16 x 32 MFMA blocks):  m = m_base + 16 mi + (lane & 15);  n = n_base + 16 nj + 4 (lane >> 4) + r
 // --------------------------------------------------------------------------------------------
 // fp32 outputs: 16 pieces of 32 rows x 32 columns (128-byte row segments).  EPI_RESID_F32 keeps D pieces of the
 // residual tile in flight.  Same arithmetic as epilogue8 (old + value).
-template <typename T, int EPI, bool FULL, int D = 4>
-ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x16 (&acc)[2][2][4], int m_base, int n_base, int lane, char* wl) {
+template <typename T, int EPI, bool FULL, int D = 4, bool NT = true>
+ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x4 (&acc)[8][8], int m_base, int n_base, int lane, char* wl) {
     if constexpr (!FULL)
         if (n_base >= p.N || m_base >= p.M) return;  // wave uniform
     float* out = reinterpret_cast<float*>(p.out);
     const int ldc = p.N;
-    const int h = lane >> 5, lm = lane & 31;
+    const int g4 = lane >> 4, l16 = lane & 15;
     f32x4 old[D][4];
     auto load_old = [&](f32x4 (&dst)[4], int piece) ESMK_INL {
         const int i = piece >> 2, jb = piece & 3;
@@ -90,12 +90,12 @@ ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x16 (&acc)[2][2][4], int m_bas
         const int i = piece >> 2, jb = piece & 3;
         char* sl = wl + (piece & 1) * 4096;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[jb >> 1][jb & 1][i][4 * g + e];
+        for (int q = 0; q < 4; ++q) {
+            const int mi2 = q >> 1, nj2 = q & 1;
+            const int row = 16 * mi2 + l16;
+            f32x4 v = acc[2 * jb + nj2][2 * i + mi2];
             if constexpr (EPI == EPI_GELU_F32) gelu_fast_x4(v);
-            *reinterpret_cast<f32x4*>(sl + lm * 128 + (((2 * g + h) ^ (lm & 7)) << 4)) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(sl + row * 128 + (((4 * nj2 + g4) ^ (row & 7)) << 4)) = v;
         }
         f32x4 vv[4];
 #pragma unroll
@@ -114,7 +114,12 @@ ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x16 (&acc)[2][2][4], int m_bas
                 v = f32x4{o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3] + v[3]};
             }
             const int m = m_base + 32 * i + r, n = n_base + 32 * jb + cc * 4;
-            if (FULL || (m < p.M && n < p.N)) *reinterpret_cast<f32x4*>(out + (size_t)m * ldc + n) = v;
+            if (FULL || (m < p.M && n < p.N)) {
+                // non-temporal: a tile's output is not read again by this launch; kept out of the way of the operand
+                // panels in the XCD's L2 (profiles/r3_gemm9_mi16_variants.log: +4 .. 7 % on the K = 1280 shapes)
+                if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (size_t)m * ldc + n));
+                else *reinterpret_cast<f32x4*>(out + (size_t)m * ldc + n) = v;
+            }
         }
         if constexpr (EPI == EPI_RESID_F32)
             if (piece + D < 16) load_old(old[piece % D], piece + D);
@@ -123,25 +128,25 @@ ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x16 (&acc)[2][2][4], int m_bas
 
 // operand-dtype outputs (EPI_STORE_T, EPI_GELU_T, EPI_QKV_ROPE): 8 rounds of 32 rows x 64 columns.  A round's 8 KiB
 // fp32 image has 256-byte rows, 16-byte chunk c of row r at slot c ^ (r & 7): conflict free for the quad writes
-// (8 lanes = 8 rows of one chunk) and for the row-major reads (16 lanes = 16 different chunks).
+// (8 lanes = 8 rows of one chunk; lane l of a 16 x 16 block holds row l & 15, chunk 4 nq + (l >> 4)) and for the
+// row-major reads (16 lanes = 16 different chunks).
 // Software pipeline over the rounds: the LDS executes a wave's accesses in order, so round r+1's writes are issued
 // right behind round r's reads and land while round r's values go through GELU / RoPE / the conversion — a single
 // wave has no partner to hide the LDS round trip behind (15.7k -> cycles of the first version were half latency).
-template <typename T, int EPI, bool FULL>
-ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x16 (&acc)[2][2][4], int m_base, int n_base, int lane, char* wl) {
+template <typename T, int EPI, bool FULL, bool NT = false>
+ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][8], int m_base, int n_base, int lane, char* wl) {
     using V8 = typename Op<T>::v8;
-    const int h = lane >> 5, lm = lane & 31;
+    const int g4 = lane >> 4, l16 = lane & 15;
     if constexpr (!FULL)
         if (m_base >= p.M) return;  // wave uniform
     auto write_round = [&](int r) ESMK_INL {
         const int hf = r >> 2, i = r & 3;
 #pragma unroll
-        for (int j2 = 0; j2 < 2; ++j2)
+        for (int mi2 = 0; mi2 < 2; ++mi2)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int chunk = 8 * j2 + 2 * g + h;
-                *reinterpret_cast<f32x4*>(wl + lm * 256 + ((chunk ^ (lm & 7)) << 4)) =
-                    f32x4{acc[hf][j2][i][4 * g], acc[hf][j2][i][4 * g + 1], acc[hf][j2][i][4 * g + 2], acc[hf][j2][i][4 * g + 3]};
+            for (int nq = 0; nq < 4; ++nq) {
+                const int row = 16 * mi2 + l16, chunk = 4 * nq + g4;
+                *reinterpret_cast<f32x4*>(wl + row * 256 + ((chunk ^ (row & 7)) << 4)) = acc[4 * hf + nq][2 * i + mi2];
             }
     };
     // raw[k]: STORE / GELU: slot k / 2 (row (64 (k/2) + lane) / 8, columns 8 (lane & 7) ..), chunk k & 1;
@@ -208,8 +213,13 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x16 (&acc)[2][2][4], int m_base,
                 for (int e = 0; e < 8; ++e) o1[e] = Op<T>::from(y1[e]), o2[e] = Op<T>::from(y2[e]);
                 if (FULL || mm < p.M) {
                     T* dst = qk + ((size_t)(b * p.H + head) * p.T + tt) * 64 + 8 * g4;
-                    *reinterpret_cast<V8*>(dst) = o1;
-                    *reinterpret_cast<V8*>(dst + 32) = o2;
+                    if constexpr (NT) {
+                        __builtin_nontemporal_store(o1, reinterpret_cast<V8*>(dst));
+                        __builtin_nontemporal_store(o2, reinterpret_cast<V8*>(dst + 32));
+                    } else {
+                        *reinterpret_cast<V8*>(dst) = o1;
+                        *reinterpret_cast<V8*>(dst + 32) = o2;
+                    }
                 }
             }
         } else {
@@ -230,7 +240,10 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x16 (&acc)[2][2][4], int m_base,
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = Op<T>::from(v[e]);
                 const int m = m_base + 32 * i + r, n = nb + 8 * c8;
-                if (FULL || (m < p.M && n < p.N)) *reinterpret_cast<V8*>(out + (size_t)m * p.N + n) = o;
+                if (FULL || (m < p.M && n < p.N)) {
+                    if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<V8*>(out + (size_t)m * p.N + n));
+                    else *reinterpret_cast<V8*>(out + (size_t)m * p.N + n) = o;
+                }
             }
         }
     };
@@ -262,13 +275,35 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     // (profiles/r3_gemm9_schedC_variants*.log): 24/52 >= 18/46 > 20/40 > 16/36 on all four layer shapes, the dense
     // issue -6 %, the stagger +-0; without the two barriers (wrong results) the kernel gains ~5 % — the chip then sits
     // on the 1400 W cap at 1.4 - 1.5 GHz, where every variant of either kernel converges to 1.1 - 1.2 PFLOP/s.
-    constexpr int M_B1 = (VAR & 3) == 2 ? 18 : (VAR & 3) == 3 ? 20 : 24;
-    constexpr int M_B2 = (VAR & 3) == 2 ? 46 : (VAR & 3) == 3 ? 40 : 52;
-    constexpr int ISSUE_STEP = (VAR & 3) == 1 ? 1 : 2;
+    // VAR & 3 (issue pattern of the 16 pieces): 0 = first barrier at slot 16, one piece per 3 slots (16 .. 61);
+    // 1 = slots 24, 25, .. 39 (dense);  2 = 24 .. 61 evenly (one per 2.5 slots);  3 = 24, 26, .. 54.
+    // A piece that finds the CU's memory pipeline busy stalls the wave's MFMA issue with it (one wave per SIMD: nobody
+    // else issues), and 4 waves x 1 piece per 2 slots is the pipeline's peak rate; measured on the four layer shapes
+    // (profiles/r3_gemm9_mi16_variants.log): pattern 0 +8 .. 9 % over 3, 2 in between, 1 -5 %.
+    constexpr int IMODE = VAR & 3;
+    constexpr int M_B1 = IMODE == 0 ? 16 : 24;
+    constexpr int M_B2 = 52;
     constexpr bool STAGGER = (VAR & 4) != 0;
     constexpr bool NO_BAR = (VAR & 8) != 0;
+    // VAR & 256 / 512 (timing experiments): the K loop of a tile starts at a K offset that depends on the workgroup
+    // (256) or on the tile's column block (512) and wraps — the vendor kernel's "StaggerU" against all CUs sweeping the
+    // same K offset of their operand rows at once.  256 changes the summation order with the tile -> workgroup map.
+    constexpr int KSTAG = (VAR & 256) ? 1 : (VAR & 512) ? 2 : 0;
+    // VAR & 1024: only the activation pieces are issued (half the DMA bytes: is the stream bound by bytes or by its
+    // round trip?);  VAR & 2048: the pieces carry the non-temporal cache policy.
+    constexpr bool HALF_DMA = (VAR & 1024) != 0;
+    constexpr int DMA_AUX = (VAR & 2048) ? 2 : 0;
     // pieces of position s+2 issued before the second barrier
-    constexpr int IN_FLIGHT = (M_B2 - M_B1 + ISSUE_STEP - 1) / ISSUE_STEP > 16 ? 16 : (M_B2 - M_B1 + ISSUE_STEP - 1) / ISSUE_STEP;
+    auto piece_slot = [](int k) constexpr {
+        return IMODE == 3 ? 24 + 2 * k : IMODE == 1 ? 24 + k : IMODE == 2 ? 24 + (k * 40) / 16 : 16 + 3 * k;
+    };
+    auto pieces_before = [piece_slot](int m) constexpr {
+        int n = 0;
+        for (int k = 0; k < 16; ++k) n += piece_slot(k) < m ? 1 : 0;
+        return n;
+    };
+    constexpr int IN_FLIGHT0 = pieces_before(M_B2);
+    constexpr int IN_FLIGHT = HALF_DMA ? (IN_FLIGHT0 + 1) / 2 : IN_FLIGHT0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -318,7 +353,9 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
         tile_coords(it, tmi, tni);
         s_it = it;
         s_kt = 0;
-        s_koff = 0;
+        if constexpr (KSTAG == 1) s_koff = (unsigned)(((blockIdx.x >> 3) & 3) * (nk >> 2)) * 128u;
+        else if constexpr (KSTAG == 2) s_koff = (unsigned)((tni & 3) * (nk >> 2)) * 128u;
+        else s_koff = 0;
         const unsigned rows_a = (unsigned)min(256, p.M - tmi * 256), rows_w = (unsigned)min(256, p.N - tni * 256);
         d_a = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(reinterpret_cast<const char*>(p.A) + (size_t)tmi * 256 * rb), 0,
                                                 (int)__builtin_amdgcn_readfirstlane(rows_a * rb), 0x00020000);
@@ -331,6 +368,8 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
         if (s_kt + 1 < nk) {
             s_kt = s_kt + 1;
             s_koff += 128u;
+            if constexpr (KSTAG != 0)
+                if (s_koff == (unsigned)nk * 128u) s_koff = 0;
         } else if (s_it + 1 < n_my) {
             set_tile(s_it + 1);
         }
@@ -338,67 +377,62 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     // piece k = 0..15: operand k & 1 (0 activations, 1 weights), rows 8 (k >> 1) .. of the wave's 64
     auto issue1 = [&](int k, int buf) ESMK_INL {
         if constexpr (!NO_DMA) {
+            if constexpr (HALF_DMA)
+                if (k & 1) return;
             const int q = k >> 1;
             char* dst = smem + buf * Q_BUF + ((k & 1) ? Q_WOFF : 0) + wave * 8192 + q * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds((k & 1) ? d_w : d_a, (lds_ptr)dst, 16, (q & 1) ? vo_odd : vo_even,
-                                                     s_koff + (unsigned)q * rb8, 0, 0);
+                                                     s_koff + (unsigned)q * rb8, 0, DMA_AUX);
         }
     };
 
-    // ---- fragments: X = K 0..31, Y = K 32..63 of a K tile; [ks & 1][32-row block] --------------------------------
-    const int lrow = (lane & 31) * 128;
-    const int swz = (lane >> 1) & 7;
-    int xo[4];
+    // ---- fragments: X = K 0..31, Y = K 32..63 of a K tile (one 16 x 16 x 32 MFMA step each); [16-row block] ---------
+    // lane l reads row l & 15 of the block, 16-byte chunk 4 half + (l >> 4) of its 128-byte row
+    const int lrow = (lane & 15) * 128;
+    const int swz = (lane >> 1) & 7;  // ((row >> 1) & 7 of the block row; blocks start at multiples of 16)
+    int xo[2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) xo[ks] = ((2 * ks + (lane >> 5)) ^ swz) << 4;
+    for (int hf = 0; hf < 2; ++hf) xo[hf] = ((4 * hf + (lane >> 4)) ^ swz) << 4;
     const int a_off = wr * 16384 + lrow;
     const int w_off = Q_WOFF + wc * 16384 + lrow;
-    V8 xa[2][4], xw[2][4], ya[2][4], yw[2][4];
+    V8 xa[8], xw[8], ya[8], yw[8];
     if constexpr (NO_RD) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xa[s][i][e] = xw[s][i][e] = ya[s][i][e] = yw[s][i][e] = Op<T>::from(0.f);
+            for (int e = 0; e < 8; ++e) xa[i][e] = xw[i][e] = ya[i][e] = yw[i][e] = Op<T>::from(0.f);
     }
-    // read r = 0..15 of a half: K sub-step 2 half + (r >> 3), block (r >> 1) & 3, r even -> activations, odd -> weights
-    auto rd1 = [&](V8 (&fa)[2][4], V8 (&fw)[2][4], const char* bp, int half, int r) ESMK_INL {
+    // read r = 0..15 of a half: block r >> 1, r even -> activations, odd -> weights
+    auto rd1 = [&](V8 (&fa)[8], V8 (&fw)[8], const char* bp, int half, int r) ESMK_INL {
         if constexpr (!NO_RD) {
-            const int k2 = r >> 3, blk = (r >> 1) & 3;
-            if (r & 1) fw[k2][blk] = *reinterpret_cast<const V8*>(bp + w_off + blk * 4096 + xo[2 * half + k2]);
-            else fa[k2][blk] = *reinterpret_cast<const V8*>(bp + a_off + blk * 4096 + xo[2 * half + k2]);
+            const int blk = r >> 1;
+            if (r & 1) fw[blk] = *reinterpret_cast<const V8*>(bp + w_off + blk * 2048 + xo[half]);
+            else fa[blk] = *reinterpret_cast<const V8*>(bp + a_off + blk * 2048 + xo[half]);
         }
     };
 
-    f32x16 acc[2][2][4];  // [64-column half][32-column block][32-row block]
-    // bv[j]: bias broadcast of 32-column block j (the C operand of a tile's first MFMAs: acc = bias + A.W^T, the order
-    // gemm8 uses).  Column n = n_base + 32 j + 8 (r >> 2) + 4 (lane >> 5) + (r & 3) sits in register r.  EPI_V_T: the
-    // bias varies with the lane, its epilogue adds it.
-    f32x16 bv[4];
+    f32x4 acc[8][8];  // [16-column block][16-row block]
+    // bv[nj]: bias of 16-column block nj (the C operand of a tile's first MFMAs: acc = bias + A.W^T, the order
+    // gemm8 uses).  Column n = n_base + 16 nj + 4 (lane >> 4) + r sits in register r.  EPI_V_T: the bias varies with
+    // the lane, its epilogue adds it.
+    f32x4 bv[8];
     // Vector loads (each lane fetches the 4 consecutive columns a register quad holds): issued BEFORE the previous
     // tile's epilogue, so they land under it — the scalar-load form cost ~2k cycles of serialized waits per tile seam.
     auto load_bias = [&](int n_base) ESMK_INL {
         bool done = false;
         if constexpr (EPI != EPI_V_T) {
             if (p.bias != nullptr) {
-                const int hsel = lane >> 5;
+                const int g4 = lane >> 4;
                 if (n_base + 128 <= p.N) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const f32x4 t = *reinterpret_cast<const f32x4*>(p.bias + n_base + 32 * j + 8 * g + 4 * hsel);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) bv[j][4 * g + e] = t[e];
-                        }
+                    for (int nj = 0; nj < 8; ++nj) bv[nj] = *reinterpret_cast<const f32x4*>(p.bias + n_base + 16 * nj + 4 * g4);
                 } else {  // N tail: clamped loads
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int nj = 0; nj < 8; ++nj)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int n = n_base + 32 * j + 8 * (r >> 2) + 4 * hsel + (r & 3);
-                            bv[j][r] = n < p.N ? p.bias[n] : 0.f;
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = n_base + 16 * nj + 4 * g4 + r;
+                            bv[nj][r] = n < p.N ? p.bias[n] : 0.f;
                         }
                 }
                 done = true;
@@ -406,23 +440,26 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
         }
         if (!done) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) bv[j][r] = 0.f;
+            for (int nj = 0; nj < 8; ++nj) bv[nj] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    // MFMA of slot m: K sub-step (m >> 4), column block j = (m >> 2) & 3, row block i = m & 3
-    auto mma1 = [&](const V8 (&fa)[2][4], const V8 (&fw)[2][4], int m, bool first) ESMK_INL {
-        const int k2 = (m >> 4) & 1, j = (m >> 2) & 3, i = m & 3;
-        f32x16& c = acc[j >> 1][j & 1][i];
-        const bool use_b = first && m < 16;  // the tile's first sub-step: C operand = bias broadcast
-        if constexpr (NO_MFMA) {
-            asm volatile("" ::"v"(fa[k2][i]), "v"(fw[k2][j]));
-            if (use_b) c = bv[j];
-        } else if constexpr (EPI == EPI_V_T) {  // lane owns 4 consecutive tokens of one channel
-            c = use_b ? Op<T>::mma(fa[k2][i], fw[k2][j], bv[j]) : Op<T>::mma(fa[k2][i], fw[k2][j], c);
-        } else {  // lane owns 4 consecutive channels of one token
-            c = use_b ? Op<T>::mma(fw[k2][j], fa[k2][i], bv[j]) : Op<T>::mma(fw[k2][j], fa[k2][i], c);
+    // the two MFMAs of slot m (16 x 16 x 32: 16 cycles each): K half m >> 5, block pair 2 (m & 31), 2 (m & 31) + 1 of the
+    // half's 64 (column block nj = idx >> 3, row block mi = idx & 7)
+    auto mma1 = [&](const V8 (&fa)[8], const V8 (&fw)[8], int m, bool first) ESMK_INL {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int idx = 2 * (m & 31) + pp;
+            const int nj = idx >> 3, mi = idx & 7;
+            f32x4& c = acc[nj][mi];
+            const bool use_b = first && m < 32;  // the tile's first K half: C operand = bias
+            if constexpr (NO_MFMA) {
+                asm volatile("" ::"v"(fa[mi]), "v"(fw[nj]));
+                if (use_b) c = bv[nj];
+            } else if constexpr (EPI == EPI_V_T) {  // lane owns 4 consecutive tokens of one channel
+                c = use_b ? Op<T>::mma16(fa[mi], fw[nj], bv[nj]) : Op<T>::mma16(fa[mi], fw[nj], c);
+            } else {  // lane owns 4 consecutive channels of one token
+                c = use_b ? Op<T>::mma16(fw[nj], fa[mi], bv[nj]) : Op<T>::mma16(fw[nj], fa[mi], c);
+            }
         }
     };
 
@@ -447,14 +484,16 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
             if (m < 32) mma1(xa, xw, m, first);
             else mma1(ya, yw, m, first);
             if (m < 16) rd1(ya, yw, sb, 1, m);
-            if constexpr (STAGGER) {  // (ISSUE_STEP == 2) even waves: slots M_B1, M_B1 + 2, ...; odd waves: one slot later
+            if constexpr (STAGGER) {  // (with pattern 3) even waves: slots M_B1, M_B1 + 2, ...; odd waves: one slot later
                 if (m >= M_B1 && m < M_B1 + 32 && ((m - M_B1) & 1) == 0) {
                     if (!(wave & 1)) issue1((m - M_B1) >> 1, cur);
                 } else if (m > M_B1 && m < M_B1 + 33 && ((m - M_B1) & 1) == 1) {
                     if (wave & 1) issue1((m - M_B1 - 1) >> 1, cur);
                 }
-            } else if (m >= M_B1 && m < M_B1 + 16 * ISSUE_STEP && ((m - M_B1) % ISSUE_STEP) == 0) {
-                issue1((m - M_B1) / ISSUE_STEP, cur);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (piece_slot(k) == m) issue1(k, cur);
             }
             if constexpr (M_B2 + 16 <= 64) {
                 if (m >= M_B2 && m < M_B2 + 16) rd1(xa, xw, sn, 0, m - M_B2);
@@ -476,7 +515,7 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     advance();
 #pragma unroll
     for (int k = 0; k < 16; ++k) issue1(k, 1);
-    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(HALF_DMA ? 8 : 16) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) rd1(xa, xw, smem, 0, r);
@@ -518,11 +557,9 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
         const bool full = (m_base + 128 <= p.M) && (n_base + 128 <= p.N);
         if constexpr (NO_EPI) {
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
+            for (int nj = 0; nj < 8; ++nj)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) asm volatile("" ::"a"(acc[hf][j][i]));
+                for (int mi = 0; mi < 8; ++mi) asm volatile("" ::"a"(acc[nj][mi]));
         } else if constexpr (EPI == EPI_STORE_F32 || EPI == EPI_GELU_F32 || EPI == EPI_RESID_F32) {
             if (full) epilogue9_f32<T, EPI, true>(p, acc, m_base, n_base, lane, slice);
             else epilogue9_f32<T, EPI, false>(p, acc, m_base, n_base, lane, slice);
@@ -531,12 +568,12 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
             for (int hf = 0; hf < 2; ++hf) {
                 const int nb = n_base + 64 * hf;
                 const bool f2 = (m_base + 128 <= p.M) && (nb + 64 <= p.N) && (p.T % 32 == 0);
-                if (f2) epilogue8<T, EPI, true, false, false, 4>(p, acc[hf], m_base, nb, lane, slice + hf * 4096, 0, 0, 0);
-                else epilogue8<T, EPI, false, false, false, 4>(p, acc[hf], m_base, nb, lane, slice + hf * 4096, 0, 0, 0);
+                if (f2) epilogue8m<T, EPI, true, false, false, 4, 8, true>(p, acc, 4 * hf, m_base, nb, lane, slice + hf * 4096, 0, 0, 0);
+                else epilogue8m<T, EPI, false, false, false, 4, 8, true>(p, acc, 4 * hf, m_base, nb, lane, slice + hf * 4096, 0, 0, 0);
             }
         } else {
-            if (full) epilogue9_t<T, EPI, true>(p, acc, m_base, n_base, lane, slice);
-            else epilogue9_t<T, EPI, false>(p, acc, m_base, n_base, lane, slice);
+            if (full) epilogue9_t<T, EPI, true, (VAR & 4096) == 0>(p, acc, m_base, n_base, lane, slice);
+            else epilogue9_t<T, EPI, false, (VAR & 4096) == 0>(p, acc, m_base, n_base, lane, slice);
         }
         if constexpr (!BIAS_EARLY) next_bias();
         stamp(it, 2);
@@ -594,6 +631,19 @@ bool gemm9_supports(const GemmArgs& p, int epi) {
 
 template <typename T>
 static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st) {
+#define ESMK_G9_ALL(V)                                                       \
+    switch (epi) {                                                            \
+        case EPI_STORE_T: return launch9<T, EPI_STORE_T, V>(p, st);           \
+        case EPI_STORE_F32: return launch9<T, EPI_STORE_F32, V>(p, st);       \
+        case EPI_GELU_T: return launch9<T, EPI_GELU_T, V>(p, st);             \
+        case EPI_GELU_F32: return launch9<T, EPI_GELU_F32, V>(p, st);         \
+        case EPI_RESID_F32: return launch9<T, EPI_RESID_F32, V>(p, st);       \
+        case EPI_QKV_ROPE: return launch9<T, EPI_QKV_ROPE, V>(p, st);         \
+        case EPI_V_T: return launch9<T, EPI_V_T, V>(p, st);                   \
+    }
+    if (var == 2) { ESMK_G9_ALL(2) }  // A/B of the issue patterns in the whole forward (ESMK_GEMM_IMPL=9:2 / 9:3)
+    if (var == 3) { ESMK_G9_ALL(3) }
+#undef ESMK_G9_ALL
     if (var == 0) {
         switch (epi) {
             case EPI_STORE_T: return launch9<T, EPI_STORE_T>(p, st);
@@ -609,10 +659,7 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
         if (epi == EPI_STORE_T) {  // timing experiments (tools/bench_gemm9.py --dbg)
             switch (var) {
                 case 1: return launch9<T, EPI_STORE_T, 1>(p, st);
-                case 2: return launch9<T, EPI_STORE_T, 2>(p, st);
-                case 3: return launch9<T, EPI_STORE_T, 3>(p, st);
-                case 4: return launch9<T, EPI_STORE_T, 4>(p, st);
-                case 5: return launch9<T, EPI_STORE_T, 5>(p, st);
+                case 7: return launch9<T, EPI_STORE_T, 7>(p, st);
                 case 8: return launch9<T, EPI_STORE_T, 8>(p, st);
                 case 16: return launch9<T, EPI_STORE_T, 16>(p, st);
                 case 32: return launch9<T, EPI_STORE_T, 32>(p, st);
@@ -620,6 +667,10 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
                 case 128: return launch9<T, EPI_STORE_T, 128>(p, st);
                 case 96: return launch9<T, EPI_STORE_T, 96>(p, st);
                 case 224: return launch9<T, EPI_STORE_T, 224>(p, st);
+                case 512: return launch9<T, EPI_STORE_T, 512>(p, st);    // K stagger by column block
+                case 1040: return launch9<T, EPI_STORE_T, 1040>(p, st);  // no MFMAs, half the DMA bytes
+                case 2048: return launch9<T, EPI_STORE_T, 2048>(p, st);  // non-temporal operand loads
+                case 4096: return launch9<T, EPI_STORE_T, 4096>(p, st);  // plain (temporal) stores
             }
         }
     }

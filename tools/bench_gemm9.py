@@ -56,6 +56,9 @@ def stamps(fn, ntiles, nk):
     return loop, epi, seam, ghz
 
 
+EXACT = True  # --tolerant: gemm9 and gemm8 only have to agree up to the summation order
+
+
 def check(dt):
     g = torch.Generator(device="cuda").manual_seed(1)
     rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
@@ -79,7 +82,12 @@ def check(dt):
                 set_impl(8)
                 ref = torch.nn.functional.linear(a.float(), w.float(), bias if use_bias else None)
                 for name, o in (("gemm9", outs[1]),):
-                    same = torch.equal(o, outs[0])
+                    if EXACT:
+                        same = torch.equal(o, outs[0])
+                    else:  # different MFMA shapes in the two kernels: same value up to the summation order
+                        tol = 2e-3 if o.dtype != torch.float32 else 2e-6
+                        scale = (ref.abs().max().item() + (x0.abs().max().item() if x0 is not None else 0.0))
+                        same = (o.float() - outs[0].float()).abs().max().item() <= tol * scale
                     fin = torch.isfinite(o.float()).all().item()
                     if not (same and fin):
                         bad += 1
@@ -89,7 +97,7 @@ def check(dt):
                 if epi == nat.EPI_STORE_F32:  # and gemm8 itself against fp32 torch (sanity of the reference arm)
                     e = (outs[0] - ref).abs().max().item() / ref.abs().max().item()
                     assert e < 5e-3, e
-    print(f"check {dt}: {'OK (bit-identical to gemm8 on all shapes / epilogues)' if bad == 0 else str(bad) + ' MISMATCHES'}", flush=True)
+    print(f"check {dt}: {'OK (' + ('bit-identical to' if EXACT else 'within the summation-order tolerance of') + ' gemm8 on all shapes / epilogues)' if bad == 0 else str(bad) + ' MISMATCHES'}", flush=True)
     return bad
 
 
@@ -101,9 +109,13 @@ def main():
     ap.add_argument("--check-only", action="store_true")
     ap.add_argument("--no-vendor", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--tolerant", action="store_true", help="gemm9 == gemm8 up to the fp32 summation order instead of bit for bit")
+    ap.add_argument("--cases", default="", help="comma-separated substrings of case names to run (default: all)")
     ap.add_argument("--dbg", action="store_true", help="also the timing-experiment variants of gemm9 (plain store only)")
     args = ap.parse_args()
     print("device:", torch.cuda.get_device_name(0), flush=True)
+    global EXACT
+    EXACT = not args.tolerant
     bad = 0
     # fp16 subnormal operands through the MFMA (the split-weight precision mode stores W - fp16(W), mostly subnormal)
     a1 = torch.ones(256, 64, device="cuda", dtype=torch.float16)
@@ -122,6 +134,8 @@ def main():
     cases = [("qk store", 2 * E, E, nat.EPI_STORE_T), ("v/out store", E, E, nat.EPI_STORE_T), ("out resid", E, E, nat.EPI_RESID_F32),
              ("fc1 store", F, E, nat.EPI_STORE_T), ("fc1 gelu", F, E, nat.EPI_GELU_T), ("fc2 store", E, F, nat.EPI_STORE_T),
              ("fc2 resid", E, F, nat.EPI_RESID_F32)]
+    if args.cases:
+        cases = [c for c in cases if any(k in c[0] for k in args.cases.split(","))]
     for name, N, K, epi in cases:
         a = rnd(M, K).to(dt)
         w = (rnd(N, K) / math.sqrt(K)).to(dt)
@@ -130,8 +144,8 @@ def main():
         flops = 2.0 * M * N * K
         arms = [("gemm8", 8, 0), ("gemm9", 9, 0)]
         if args.dbg and epi == nat.EPI_STORE_T:
-            arms += [("g9 dense-issue", 9, 1), ("g9 stagger", 9, 4), ("g9 b24/52", 9, 2), ("g9 no-barrier", 9, 8), ("g9 no-mfma", 9, 16), ("g9 no-dma", 9, 32), ("g9 no-reads", 9, 64), ("g9 no-epi", 9, 128),
-                     ("g9 mfma-only", 9, 96), ("g9 skeleton", 9, 224)]
+            arms += [("g9 dense", 9, 1), ("g9 spread24-61", 9, 2), ("g9 24+2k", 9, 3), ("g9 temporal-st", 9, 4096), ("g9 no-barrier", 9, 8),
+                     ("g9 no-mfma", 9, 16), ("g9 no-dma", 9, 32), ("g9 no-reads", 9, 64), ("g9 no-epi", 9, 128), ("g9 mfma-only", 9, 96)]
         times = {n: [] for n, _, _ in arms}
         if not args.no_vendor and epi == nat.EPI_STORE_T:
             times["vendor"] = []
@@ -147,11 +161,11 @@ def main():
             set_impl(impl, var)
             loop, ep, seam, ghz = stamps(lambda: ops.linear(a, w, bias, epi, out=out), min(32, nt // 256), K // 64)
             ms = statistics.median(times[n])
-            print(f"{name:12s} {n:12s} {ms*1e3:8.1f} us (min {min(times[n])*1e3:8.1f}) {flops/ms/1e9:7.1f} TFLOP/s | cycles/K-tile {loop:7.1f} "
+            print(f"{name:12s} {n:18s} {ms*1e3:8.1f} us (min {min(times[n])*1e3:8.1f}) {flops/ms/1e9:7.1f} TFLOP/s | cycles/K-tile {loop:7.1f} "
                   f"epilogue {ep:7.0f} seam {seam:6.0f} clock {ghz:4.2f} GHz", flush=True)
         if "vendor" in times:
             ms = statistics.median(times["vendor"])
-            print(f"{name:12s} {'vendor':12s} {ms*1e3:8.1f} us (min {min(times['vendor'])*1e3:8.1f}) {flops/ms/1e9:7.1f} TFLOP/s", flush=True)
+            print(f"{name:12s} {'vendor':18s} {ms*1e3:8.1f} us (min {min(times['vendor'])*1e3:8.1f}) {flops/ms/1e9:7.1f} TFLOP/s", flush=True)
         set_impl(8)
         del a, w, out
     sys.exit(1 if bad else 0)
