@@ -117,6 +117,38 @@ ESMK_DEV void gelu_fast_x4(V& v) {
     v[0] = ra.x, v[1] = ra.y, v[2] = rb.x, v[3] = rb.y;
 }
 
+// Eight values at once: FOUR interleaved Horner chains.  A dependent v_pk_fma_f32 needs ~8 cycles before its result can
+// be consumed and issues in 4, so two chains keep ONE wave's VALU half busy; kernels with two waves per SIMD fill the gaps
+// from the other wave, gemm9 (one wave per SIMD) needs the four chains in its own stream (its GELU epilogue: 15.0k ->
+// cycles per 128 x 128 block).  Bit-identical to gelu_fast per element.
+template <typename V>
+ESMK_DEV void gelu_fast_x8(V& v) {
+    constexpr float c[12] = ESMK_GELU_COEF;
+    f32x2 x[4], u[4], t[4], q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        x[k] = f32x2{v[2 * k], v[2 * k + 1]};
+        u[k].x = __builtin_amdgcn_fmed3f(x[k].x, -kGeluClamp, kGeluClamp);
+        u[k].y = __builtin_amdgcn_fmed3f(x[k].y, -kGeluClamp, kGeluClamp);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = __builtin_elementwise_fma(u[k] * kGeluK2, u[k], (f32x2)(-1.0f));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = (f32x2)(c[0]);
+#pragma unroll
+    for (int j = 1; j < 12; ++j) {
+        __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise serialises the chains again to save registers)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = __builtin_elementwise_fma(q[k], t[k], (f32x2)(c[j]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x2 r = x[k] * __builtin_elementwise_fma(u[k], q[k], (f32x2)(0.5f));
+        v[2 * k] = r.x, v[2 * k + 1] = r.y;
+    }
+}
+
 ESMK_DEV float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -375,11 +375,34 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
         return e != nullptr && strcmp(e, "old") == 0;
     }();
     if (!env_old && !p.force_old && !p.force_generic && !p.dbg && g_impl != 8 && gemm9_supports(p, epi)) {
-        if (g_impl == 9 && g_impl_var >= 0) return launch_gemm9(p, epi, operand_dtype, g_impl_var, st);
-        // auto: only launches that fill the chip for at least one round (small batches keep gemm8's half-height tiles)
-        const long long tiles = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-        if (((g_mask9 >> epi) & 1) && (epi != EPI_RESID_F32 || p.K >= g_mink9) && tiles >= 256)
-            return launch_gemm9(p, epi, operand_dtype, g_auto_var, st);
+        static const bool hm9 = [] { const char* e = getenv("ESMK_GEMM9_HM"); return e == nullptr || atoi(e) != 0; }();
+        if (g_impl == 9 && g_impl_var >= 0) {
+            return launch_gemm9(p, epi, operand_dtype, g_impl_var, st);
+        }
+        // auto: tile height by rounds over the CUs x cost of a tile (a half-height tile costs ~0.58 of a full one:
+        // 1470 against 2400 - 2600 cycles per K tile, profiles/r3_gemm9_half_height_b4.log).  ESMK_GEMM9_POLICY=0: the
+        // round-3a rule (gemm9 for >= 256 full tiles or where gemm8 would take half-height tiles, gemm8 otherwise).
+        static const int policy = [] { const char* e = getenv("ESMK_GEMM9_POLICY"); return e ? atoi(e) : 1; }();
+        const long long tn = (p.N + 255) / 256;
+        const long long tiles = (long long)((p.M + 255) / 256) * tn, tiles_h = (long long)((p.M + 127) / 128) * tn;
+        if (((g_mask9 >> epi) & 1) && (epi != EPI_RESID_F32 || p.K >= g_mink9)) {
+            bool half, use9;
+            if (policy == 0) {
+                half = p.half_m > 0 || (p.half_m == 0 && tiles < 256 && gemm8_half_height(p));
+                use9 = half ? hm9 : tiles >= 256;
+            } else {
+                const double wg = 256.0;
+                const double cost_f = (double)((tiles + 255) / 256), cost_h = 0.58 * (double)((tiles_h + 255) / 256);
+                (void)wg;
+                half = p.half_m > 0 || (p.half_m == 0 && cost_h < 0.92 * cost_f);
+                use9 = true;
+            }
+            if (use9) {
+                GemmArgs q = p;
+                q.half_m = half ? 1 : 0;
+                return launch_gemm9(q, epi, operand_dtype, half ? 0 : g_auto_var, st);
+            }
+        }
     }
     if (!env_old && !p.force_old && !p.force_generic && gemm8_supports(p, epi))
         return launch_gemm8(p, epi, operand_dtype, st);

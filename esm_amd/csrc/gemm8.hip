@@ -185,8 +185,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
         sP.kt = 0;
         const int row = (wave & 3) * 64 + lane;
         if (wave < 4) {
-            sP.base = reinterpret_cast<const char*>(p.A) + (size_t)tmi * 256 * a_rb;
-            sP.off0 = (unsigned)min(row, p.M - tmi * 256 - 1) * a_rb;
+            sP.base = reinterpret_cast<const char*>(p.A) + (size_t)tmi * TM * a_rb;  // (HM: rows 128.. are the next tile's)
+            sP.off0 = (unsigned)min(row, p.M - tmi * TM - 1) * a_rb;
         } else {
             sP.base = reinterpret_cast<const char*>(p.W) + (size_t)tni * 256 * w_rb;
             sP.off0 = (unsigned)min(row, p.N - tni * 256 - 1) * w_rb;
@@ -276,7 +276,6 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p, unsigned long
     // acc = bias (the nn.Linear bias rides through the K loop; fp32).  The wave's 64 bias values are
     // fetched with SCALAR loads through the constant address space: they do not enter the vmcnt queue,
     // so they neither wait for the LDS-DMA stream nor for the previous epilogue's stores.
-    typedef const __attribute__((address_space(4))) float* cfloat_ptr;
     auto init_acc = [&](int n_base) {
         bool done = false;
         if constexpr (EPI != EPI_V_T) {
@@ -629,6 +628,18 @@ static hipError_t dispatch8(const GemmArgs& p, int epi, hipStream_t st) {
         if (mode == 4) { ESMK_CASES(0, 128, 0) }
     }
     if (gemm8_half_height(p)) {
+        // ESMK_HM_PF=4 (experiment): half-height launches (small batches: latency bound, operands come from the MALL)
+        // with the L2 prefetch stream four K tiles ahead
+        static const int hm_pf = [] { const char* e = getenv("ESMK_HM_PF"); return e ? atoi(e) : 0; }();
+        if (hm_pf == 4) {
+            switch (epi) {
+                case EPI_STORE_T: return launch8<T, EPI_STORE_T, 0, 0, 4, false, true>(p, st);
+                case EPI_GELU_T: return launch8<T, EPI_GELU_T, 0, 0, 4, false, true>(p, st);
+                case EPI_RESID_F32: return launch8<T, EPI_RESID_F32, 0, 0, 4, false, true>(p, st);
+                case EPI_QKV_ROPE: return launch8<T, EPI_QKV_ROPE, 0, 0, 4, false, true>(p, st);
+                case EPI_V_T: return launch8<T, EPI_V_T, 0, 0, 4, false, true>(p, st);
+            }
+        }
         switch (epi) {
             case EPI_STORE_T: return launch8<T, EPI_STORE_T, 0, 0, 0, false, true>(p, st);
             case EPI_STORE_F32: return launch8<T, EPI_STORE_F32, 0, 0, 0, false, true>(p, st);

@@ -63,8 +63,12 @@ constexpr int Q_LDS = Q_EPI + 4 * Q_SLICE;   // 160 KiB
 // --------------------------------------------------------------------------------------------
 // fp32 outputs: 16 pieces of 32 rows x 32 columns (128-byte row segments).  EPI_RESID_F32 keeps D pieces of the
 // residual tile in flight.  Same arithmetic as epilogue8 (old + value).
-template <typename T, int EPI, bool FULL, int D = 4, bool NT = true>
-ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x4 (&acc)[8][8], int m_base, int n_base, int lane, char* wl) {
+// NMI = 16-row blocks of the wave's block: 8 (128 rows), or 4 in the half-height kernel (64 rows).
+// SB: one 4 KiB piece buffer instead of two (the three-stage half-height kernel has 4 KiB of slice per wave; the LDS
+// executes a wave's accesses in order, so re-using the buffer is safe, only the overlap of write and read is lost).
+template <typename T, int EPI, bool FULL, int D = 4, bool NT = true, int NMI = 8, bool SB = false>
+ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base, int n_base, int lane, char* wl) {
+    constexpr int NP = 2 * NMI;  // pieces of 32 x 32
     if constexpr (!FULL)
         if (n_base >= p.N || m_base >= p.M) return;  // wave uniform
     float* out = reinterpret_cast<float*>(p.out);
@@ -86,9 +90,9 @@ ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x4 (&acc)[8][8], int m_base, i
         for (int d = 0; d < D; ++d) load_old(old[d], d);
     }
 #pragma unroll
-    for (int piece = 0; piece < 16; ++piece) {
+    for (int piece = 0; piece < NP; ++piece) {
         const int i = piece >> 2, jb = piece & 3;
-        char* sl = wl + (piece & 1) * 4096;
+        char* sl = wl + (SB ? 0 : (piece & 1) * 4096);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int mi2 = q >> 1, nj2 = q & 1;
@@ -122,7 +126,7 @@ ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x4 (&acc)[8][8], int m_base, i
             }
         }
         if constexpr (EPI == EPI_RESID_F32)
-            if (piece + D < 16) load_old(old[piece % D], piece + D);
+            if (piece + D < NP) load_old(old[piece % D], piece + D);
     }
 }
 
@@ -133,20 +137,24 @@ ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x4 (&acc)[8][8], int m_base, i
 // Software pipeline over the rounds: the LDS executes a wave's accesses in order, so round r+1's writes are issued
 // right behind round r's reads and land while round r's values go through GELU / RoPE / the conversion — a single
 // wave has no partner to hide the LDS round trip behind (15.7k -> cycles of the first version were half latency).
-template <typename T, int EPI, bool FULL, bool NT = false>
-ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][8], int m_base, int n_base, int lane, char* wl) {
+// RR = rows per round: 32 (8 KiB image), or 16 (4 KiB: the three-stage half-height kernel).
+template <typename T, int EPI, bool FULL, bool NT = false, int NMI = 8, int RR = 32>
+ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base, int n_base, int lane, char* wl) {
     using V8 = typename Op<T>::v8;
+    constexpr int NI = NMI * 16 / RR;  // row blocks of RR rows
+    constexpr int NR = 2 * NI;         // rounds: [64-column half][row block]
+    constexpr int MB = RR / 16;        // 16-row MFMA blocks per round
     const int g4 = lane >> 4, l16 = lane & 15;
     if constexpr (!FULL)
         if (m_base >= p.M) return;  // wave uniform
     auto write_round = [&](int r) ESMK_INL {
-        const int hf = r >> 2, i = r & 3;
+        const int hf = r / NI, i = r % NI;
 #pragma unroll
-        for (int mi2 = 0; mi2 < 2; ++mi2)
+        for (int mi2 = 0; mi2 < MB; ++mi2)
 #pragma unroll
             for (int nq = 0; nq < 4; ++nq) {
                 const int row = 16 * mi2 + l16, chunk = 4 * nq + g4;
-                *reinterpret_cast<f32x4*>(wl + row * 256 + ((chunk ^ (row & 7)) << 4)) = acc[4 * hf + nq][2 * i + mi2];
+                *reinterpret_cast<f32x4*>(wl + row * 256 + ((chunk ^ (row & 7)) << 4)) = acc[4 * hf + nq][MB * i + mi2];
             }
     };
     // raw[k]: STORE / GELU: slot k / 2 (row (64 (k/2) + lane) / 8, columns 8 (lane & 7) ..), chunk k & 1;
@@ -154,7 +162,7 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][8], int m_base, int
     auto read_round = [&](f32x4 (&raw)[8]) ESMK_INL {
         if constexpr (EPI == EPI_QKV_ROPE) {
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
+            for (int it = 0; it < RR / 16; ++it) {
                 const int slot = it * 64 + lane;
                 const int r = slot >> 2, g4 = slot & 3;
 #pragma unroll
@@ -165,7 +173,7 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][8], int m_base, int
             }
         } else {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
+            for (int it = 0; it < RR / 8; ++it) {
                 const int slot = it * 64 + lane;
                 const int r = slot >> 3, c8 = slot & 7;
 #pragma unroll
@@ -175,7 +183,7 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][8], int m_base, int
         }
     };
     auto finish_round = [&](int rd, const f32x4 (&raw)[8]) ESMK_INL {
-        const int hf = rd >> 2, i = rd & 3;
+        const int hf = rd / NI, i = rd % NI;
         const int nb = n_base + 64 * hf;
         if constexpr (!FULL)
             if (nb >= p.N) return;  // wave uniform
@@ -187,10 +195,10 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][8], int m_base, int
             T* qk = reinterpret_cast<T*>(which == 0 ? p.q : p.k);
             const float sc = which == 0 ? p.scaling : 1.0f;
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
+            for (int it = 0; it < RR / 16; ++it) {
                 const int slot = it * 64 + lane;
                 const int r = slot >> 2, g4 = slot & 3;  // row of the round, dims [8 g4, 8 g4 + 8)
-                const int mm = m_base + 32 * i + r;
+                const int mm = m_base + RR * i + r;
                 const int m = FULL ? mm : min(mm, p.M - 1);
                 const int b = m / p.T, tt = m - b * p.T;
                 float y1[8], y2[8];
@@ -225,21 +233,19 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][8], int m_base, int
         } else {
             T* out = reinterpret_cast<T*>(p.out);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
+            for (int it = 0; it < RR / 8; ++it) {
                 const int slot = it * 64 + lane;
                 const int r = slot >> 3, c8 = slot & 7;  // row of the round, columns [8 c8, 8 c8 + 8)
                 float v[8];
 #pragma unroll
-                for (int e2 = 0; e2 < 2; ++e2) {
-                    float t4[4] = {raw[2 * it + e2][0], raw[2 * it + e2][1], raw[2 * it + e2][2], raw[2 * it + e2][3]};
-                    if constexpr (EPI == EPI_GELU_T) gelu_fast_x4(t4);
+                for (int e2 = 0; e2 < 2; ++e2)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * e2 + e] = t4[e];
-                }
+                    for (int e = 0; e < 4; ++e) v[4 * e2 + e] = raw[2 * it + e2][e];
+                if constexpr (EPI == EPI_GELU_T) gelu_fast_x8(v);  // four chains: one wave per SIMD has no partner to fill VALU gaps
                 V8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = Op<T>::from(v[e]);
-                const int m = m_base + 32 * i + r, n = nb + 8 * c8;
+                const int m = m_base + RR * i + r, n = nb + 8 * c8;
                 if (FULL || (m < p.M && n < p.N)) {
                     if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<V8*>(out + (size_t)m * p.N + n));
                     else *reinterpret_cast<V8*>(out + (size_t)m * p.N + n) = o;
@@ -249,10 +255,10 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][8], int m_base, int
     };
     write_round(0);
 #pragma unroll
-    for (int rd = 0; rd < 8; ++rd) {
+    for (int rd = 0; rd < NR; ++rd) {
         f32x4 raw[8];
         read_round(raw);
-        if (rd + 1 < 8) write_round(rd + 1);
+        if (rd + 1 < NR) write_round(rd + 1);
         __builtin_amdgcn_sched_barrier(0);  // the next round's LDS traffic is issued before this round's arithmetic
         finish_round(rd, raw);
     }
@@ -262,27 +268,41 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][8], int m_base, int
 // kernel.  VAR = timing experiments (results are wrong): 16 no MFMA, 32 no LDS-DMA, 64 no fragment reads,
 // 128 no epilogue.
 // --------------------------------------------------------------------------------------------
-template <typename T, int EPI, int VAR = 0>
+// HM: half-height tiles (128 x 256; wave blocks 64 x 128) for launches that leave CUs idle with 256-row tiles (small
+// batches).  Same LDS image (the activation half of a buffer is half used), 4 + 8 pieces per wave and K tile, 32 MFMA
+// slots; every output element sees the same MFMA sequence over K as in the full-height kernel: same bits.
+template <typename T, int EPI, int VAR = 0, bool HM = false>
 __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long long* timing) {
+    constexpr int TM = HM ? 128 : 256;     // tile height
+    constexpr int NMI = HM ? 4 : 8;        // 16-row blocks of a wave's block
+    constexpr int NPC = NMI + 8;           // DMA pieces per wave and K tile
+    constexpr int NRD = NMI + 8;           // fragment reads per K half
+    constexpr int NS = 8 * NMI;            // MFMA slots (two MFMAs each) per K tile
+    // LDS: full height: two K-tile buffers of 64 KiB + 4 x 8 KiB epilogue slices;  HM: THREE buffers of 48 KiB (128
+    // activation rows + 256 weight rows) + 4 x 4 KiB slices — with half the MFMAs per K tile a piece issued two K tiles
+    // ahead has less than the MALL round trip to land (small batches are latency bound), three ahead it has.
+    constexpr int NST = HM ? 3 : 2;
+    constexpr int BUF = HM ? 49152 : Q_BUF, WOFF = HM ? 16384 : Q_WOFF;
+    constexpr int SLICE = HM ? 4096 : Q_SLICE;
+    static_assert(NST * BUF + 4 * SLICE <= Q_LDS, "LDS budget");
+    static_assert(!HM || (VAR & ~(8 | 16 | 32 | 64 | 128)) == 0, "half-height tiles: only the timing-experiment bits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V8 = typename Op<T>::v8;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     constexpr bool NO_MFMA = (VAR & 16) != 0, NO_DMA = (VAR & 32) != 0, NO_RD = (VAR & 64) != 0, NO_EPI = (VAR & 128) != 0;
-    // slots of the two barriers (VAR & 3: placement experiments; VAR & 8: without the s_barrier, results wrong)
-    // measured (profiles/r3_gemm9_schedC_variants.log): 18/46 beats 20/40, 16/36 and 24/44 on all four layer shapes
-    // VAR & 3: 1 = one piece per slot instead of every other slot, 2 = 18/46, 3 = 20/40;
-    // VAR & 4: odd waves issue their pieces one slot later than even waves (half the TA burst).  Measured
-    // (profiles/r3_gemm9_schedC_variants*.log): 24/52 >= 18/46 > 20/40 > 16/36 on all four layer shapes, the dense
-    // issue -6 %, the stagger +-0; without the two barriers (wrong results) the kernel gains ~5 % — the chip then sits
-    // on the 1400 W cap at 1.4 - 1.5 GHz, where every variant of either kernel converges to 1.1 - 1.2 PFLOP/s.
+    // VAR & 4: odd waves issue their pieces one slot later than even waves (half the TA burst): +-0.
+    // VAR & 8: without the s_barrier (results wrong): +3 .. 7 %.
     // VAR & 3 (issue pattern of the 16 pieces): 0 = first barrier at slot 16, one piece per 3 slots (16 .. 61);
     // 1 = slots 24, 25, .. 39 (dense);  2 = 24 .. 61 evenly (one per 2.5 slots);  3 = 24, 26, .. 54.
     // A piece that finds the CU's memory pipeline busy stalls the wave's MFMA issue with it (one wave per SIMD: nobody
     // else issues), and 4 waves x 1 piece per 2 slots is the pipeline's peak rate; measured on the four layer shapes
     // (profiles/r3_gemm9_mi16_variants.log): pattern 0 +8 .. 9 % over 3, 2 in between, 1 -5 %.
+    // HM (32 slots, three buffers): Y reads two per slot in slots 0 .. 5, first barrier at 8, the 12 pieces of position
+    // s+3 at slots 8, 10, .. 30, second barrier at 16 (the pieces of position s+1 were issued two K tiles ago), X reads of
+    // position s+1 one per slot in 16 .. 27.
     constexpr int IMODE = VAR & 3;
-    constexpr int M_B1 = IMODE == 0 ? 16 : 24;
-    constexpr int M_B2 = 52;
+    constexpr int M_B1 = HM ? 8 : (IMODE == 0 ? 16 : 24);
+    constexpr int M_B2 = HM ? 16 : 52;
     constexpr bool STAGGER = (VAR & 4) != 0;
     constexpr bool NO_BAR = (VAR & 8) != 0;
     // VAR & 256 / 512 (timing experiments): the K loop of a tile starts at a K offset that depends on the workgroup
@@ -295,15 +315,16 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     constexpr int DMA_AUX = (VAR & 2048) ? 2 : 0;
     // pieces of position s+2 issued before the second barrier
     auto piece_slot = [](int k) constexpr {
+        if (HM) return 8 + 2 * k;
         return IMODE == 3 ? 24 + 2 * k : IMODE == 1 ? 24 + k : IMODE == 2 ? 24 + (k * 40) / 16 : 16 + 3 * k;
     };
     auto pieces_before = [piece_slot](int m) constexpr {
         int n = 0;
-        for (int k = 0; k < 16; ++k) n += piece_slot(k) < m ? 1 : 0;
+        for (int k = 0; k < NPC; ++k) n += piece_slot(k) < m ? 1 : 0;
         return n;
     };
     constexpr int IN_FLIGHT0 = pieces_before(M_B2);
-    constexpr int IN_FLIGHT = HALF_DMA ? (IN_FLIGHT0 + 1) / 2 : IN_FLIGHT0;
+    constexpr int IN_FLIGHT = HALF_DMA ? (IN_FLIGHT0 + 1) / 2 : IN_FLIGHT0 + (HM ? NPC : 0);  // HM: + position s+2
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -312,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     const unsigned rb = (unsigned)p.K * 2u;  // operand row stride in bytes
 
     // ---- static persistent schedule (gemm8's: XCD-contiguous ranges of a column-panel blocked tile order) ----
-    const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
+    const int tiles_m = (p.M + TM - 1) / TM, tiles_n = (p.N + 255) >> 8;
     const int total = tiles_m * tiles_n;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     const int q8 = total >> 3, r8 = total & 7;
@@ -345,9 +366,13 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     unsigned s_koff;
     const unsigned rb8 = 8u * rb;
     // (row >> 1) & 7 of row = 64 wave + 8 q + lane / 8:  4 (q & 1) + ((lane >> 4) & 3)
+    // (HM: the wave stages activation rows [32 wave, + 32) — the same swizzle term — and weight rows [64 wave, + 64))
     const unsigned vo_base = (unsigned)(64 * wave + (lane >> 3)) * rb;
     const unsigned vo_even = vo_base + (unsigned)(((lane & 7) ^ ((lane >> 4) & 3)) << 4);
     const unsigned vo_odd = vo_base + (unsigned)(((lane & 7) ^ (4 + ((lane >> 4) & 3))) << 4);
+    const unsigned va_base = (unsigned)(32 * wave + (lane >> 3)) * rb;
+    const unsigned va_even = HM ? va_base + (unsigned)(((lane & 7) ^ ((lane >> 4) & 3)) << 4) : vo_even;
+    const unsigned va_odd = HM ? va_base + (unsigned)(((lane & 7) ^ (4 + ((lane >> 4) & 3))) << 4) : vo_odd;
     auto set_tile = [&](int it) ESMK_INL {
         int tmi, tni;
         tile_coords(it, tmi, tni);
@@ -356,8 +381,8 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
         if constexpr (KSTAG == 1) s_koff = (unsigned)(((blockIdx.x >> 3) & 3) * (nk >> 2)) * 128u;
         else if constexpr (KSTAG == 2) s_koff = (unsigned)((tni & 3) * (nk >> 2)) * 128u;
         else s_koff = 0;
-        const unsigned rows_a = (unsigned)min(256, p.M - tmi * 256), rows_w = (unsigned)min(256, p.N - tni * 256);
-        d_a = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(reinterpret_cast<const char*>(p.A) + (size_t)tmi * 256 * rb), 0,
+        const unsigned rows_a = (unsigned)min(TM, p.M - tmi * TM), rows_w = (unsigned)min(256, p.N - tni * 256);
+        d_a = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(reinterpret_cast<const char*>(p.A) + (size_t)tmi * TM * rb), 0,
                                                 (int)__builtin_amdgcn_readfirstlane(rows_a * rb), 0x00020000);
         d_w = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(reinterpret_cast<const char*>(p.W) + (size_t)tni * 256 * rb), 0,
                                                 (int)__builtin_amdgcn_readfirstlane(rows_w * rb), 0x00020000);
@@ -375,13 +400,16 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
         }
     };
     // piece k = 0..15: operand k & 1 (0 activations, 1 weights), rows 8 (k >> 1) .. of the wave's 64
+    // (HM: k = 0..3 activations, rows 8 k .. of the wave's 32; k = 4..11 weights)
     auto issue1 = [&](int k, int buf) ESMK_INL {
         if constexpr (!NO_DMA) {
             if constexpr (HALF_DMA)
                 if (k & 1) return;
-            const int q = k >> 1;
-            char* dst = smem + buf * Q_BUF + ((k & 1) ? Q_WOFF : 0) + wave * 8192 + q * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds((k & 1) ? d_w : d_a, (lds_ptr)dst, 16, (q & 1) ? vo_odd : vo_even,
+            const bool isw = HM ? (k >= 4) : ((k & 1) != 0);
+            const int q = HM ? (isw ? k - 4 : k) : (k >> 1);
+            char* dst = smem + buf * BUF + (isw ? WOFF + wave * 8192 : wave * (HM ? 4096 : 8192)) + q * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(isw ? d_w : d_a, (lds_ptr)dst, 16,
+                                                     isw ? ((q & 1) ? vo_odd : vo_even) : ((q & 1) ? va_odd : va_even),
                                                      s_koff + (unsigned)q * rb8, 0, DMA_AUX);
         }
     };
@@ -393,25 +421,34 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     int xo[2];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) xo[hf] = ((4 * hf + (lane >> 4)) ^ swz) << 4;
-    const int a_off = wr * 16384 + lrow;
-    const int w_off = Q_WOFF + wc * 16384 + lrow;
-    V8 xa[8], xw[8], ya[8], yw[8];
+    const int a_off = wr * (NMI * 2048) + lrow;
+    const int w_off = WOFF + wc * 16384 + lrow;
+    V8 xa[NMI], xw[8], ya[NMI], yw[8];
     if constexpr (NO_RD) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xa[i][e] = xw[i][e] = ya[i][e] = yw[i][e] = Op<T>::from(0.f);
+            for (int e = 0; e < 8; ++e) {
+                xw[i][e] = yw[i][e] = Op<T>::from(0.f);
+                if (i < NMI) xa[i][e] = ya[i][e] = Op<T>::from(0.f);
+            }
     }
-    // read r = 0..15 of a half: block r >> 1, r even -> activations, odd -> weights
-    auto rd1 = [&](V8 (&fa)[8], V8 (&fw)[8], const char* bp, int half, int r) ESMK_INL {
+    // read r = 0 .. NRD - 1 of a half: r < 2 NMI: block r >> 1, r even -> activations, odd -> weights; then the
+    // remaining weight blocks
+    auto rd1 = [&](V8 (&fa)[NMI], V8 (&fw)[8], const char* bp, int half, int r) ESMK_INL {
         if constexpr (!NO_RD) {
-            const int blk = r >> 1;
-            if (r & 1) fw[blk] = *reinterpret_cast<const V8*>(bp + w_off + blk * 2048 + xo[half]);
-            else fa[blk] = *reinterpret_cast<const V8*>(bp + a_off + blk * 2048 + xo[half]);
+            if (r >= 2 * NMI) {
+                const int blk = r - NMI;
+                fw[blk] = *reinterpret_cast<const V8*>(bp + w_off + blk * 2048 + xo[half]);
+            } else {
+                const int blk = r >> 1;
+                if (r & 1) fw[blk] = *reinterpret_cast<const V8*>(bp + w_off + blk * 2048 + xo[half]);
+                else fa[blk] = *reinterpret_cast<const V8*>(bp + a_off + blk * 2048 + xo[half]);
+            }
         }
     };
 
-    f32x4 acc[8][8];  // [16-column block][16-row block]
+    f32x4 acc[8][NMI];  // [16-column block][16-row block]
     // bv[nj]: bias of 16-column block nj (the C operand of a tile's first MFMAs: acc = bias + A.W^T, the order
     // gemm8 uses).  Column n = n_base + 16 nj + 4 (lane >> 4) + r sits in register r.  EPI_V_T: the bias varies with
     // the lane, its epilogue adds it.
@@ -443,15 +480,15 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
             for (int nj = 0; nj < 8; ++nj) bv[nj] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    // the two MFMAs of slot m (16 x 16 x 32: 16 cycles each): K half m >> 5, block pair 2 (m & 31), 2 (m & 31) + 1 of the
-    // half's 64 (column block nj = idx >> 3, row block mi = idx & 7)
-    auto mma1 = [&](const V8 (&fa)[8], const V8 (&fw)[8], int m, bool first) ESMK_INL {
+    // the two MFMAs of slot m (16 x 16 x 32: 16 cycles each): K half m / (NS / 2), block pair 2 m', 2 m' + 1 of the
+    // half's 8 NMI (column block nj = idx / NMI, row block mi = idx % NMI)
+    auto mma1 = [&](const V8 (&fa)[NMI], const V8 (&fw)[8], int m, bool first) ESMK_INL {
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
-            const int idx = 2 * (m & 31) + pp;
-            const int nj = idx >> 3, mi = idx & 7;
+            const int idx = 2 * (m % (NS / 2)) + pp;
+            const int nj = idx / NMI, mi = idx % NMI;
             f32x4& c = acc[nj][mi];
-            const bool use_b = first && m < 32;  // the tile's first K half: C operand = bias
+            const bool use_b = first && m < NS / 2;  // the tile's first K half: C operand = bias
             if constexpr (NO_MFMA) {
                 asm volatile("" ::"v"(fa[mi]), "v"(fw[nj]));
                 if (use_b) c = bv[nj];
@@ -465,12 +502,13 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
 
     int cur = 0;
     auto ktile = [&](bool first) ESMK_INL {
-        const char* sb = smem + cur * Q_BUF;
-        const char* sn = smem + (cur ^ 1) * Q_BUF;
-        advance();  // the stream now stands at position s+2
+        const int nxt = (cur + 1 == NST) ? 0 : cur + 1;
+        const char* sb = smem + cur * BUF;
+        const char* sn = smem + nxt * BUF;
+        advance();  // the stream now stands at position s + NST
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < 64; ++m) {
+        for (int m = 0; m < NS; ++m) {
             if (m == M_B1) {  // every wave has read buffer cur completely
                 if constexpr (NO_BAR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -481,9 +519,16 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
                 else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(IN_FLIGHT) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (m < 32) mma1(xa, xw, m, first);
+            if (m < NS / 2) mma1(xa, xw, m, first);
             else mma1(ya, yw, m, first);
-            if (m < 16) rd1(ya, yw, sb, 1, m);
+            if constexpr (HM) {
+                if (m < NRD / 2) {
+                    rd1(ya, yw, sb, 1, 2 * m);
+                    rd1(ya, yw, sb, 1, 2 * m + 1);
+                }
+            } else {
+                if (m < NRD) rd1(ya, yw, sb, 1, m);
+            }
             if constexpr (STAGGER) {  // (with pattern 3) even waves: slots M_B1, M_B1 + 2, ...; odd waves: one slot later
                 if (m >= M_B1 && m < M_B1 + 32 && ((m - M_B1) & 1) == 0) {
                     if (!(wave & 1)) issue1((m - M_B1) >> 1, cur);
@@ -492,33 +537,36 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < 16; ++k)
+                for (int k = 0; k < NPC; ++k)
                     if (piece_slot(k) == m) issue1(k, cur);
             }
-            if constexpr (M_B2 + 16 <= 64) {
-                if (m >= M_B2 && m < M_B2 + 16) rd1(xa, xw, sn, 0, m - M_B2);
+            if constexpr (M_B2 + NRD <= NS) {
+                if (m >= M_B2 && m < M_B2 + NRD) rd1(xa, xw, sn, 0, m - M_B2);
             } else {  // late second barrier: two reads per slot
-                if (m >= M_B2 && m < M_B2 + 8) {
+                if (m >= M_B2 && m < M_B2 + NRD / 2) {
                     rd1(xa, xw, sn, 0, 2 * (m - M_B2));
                     rd1(xa, xw, sn, 0, 2 * (m - M_B2) + 1);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        cur ^= 1;
+        cur = nxt;
     };
 
     // ---- prologue: positions 0 and 1 on their way, X fragments of position 0 in registers -------------------------
     set_tile(0);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) issue1(k, 0);
-    advance();
+    for (int k = 0; k < NPC; ++k) issue1(k, 0);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) issue1(k, 1);
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(HALF_DMA ? 8 : 16) : "memory");
+    for (int st = 1; st < NST; ++st) {
+        advance();
+#pragma unroll
+        for (int k = 0; k < NPC; ++k) issue1(k, st);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(HALF_DMA ? 8 : (NST - 1) * NPC) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rd1(xa, xw, smem, 0, r);
+    for (int r = 0; r < NRD; ++r) rd1(xa, xw, smem, 0, r);
 
     auto stamp = [&](int it, int k) ESMK_INL {
         if (timing != nullptr && tid == 0) {
@@ -536,7 +584,8 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     for (int it = 0; it < n_my; ++it) {
         int tmi, tni;
         tile_coords(it, tmi, tni);
-        const int m_base = tmi * 256 + wr * 128, n_base = tni * 256 + wc * 128;
+        constexpr int WRM = TM / 2;  // rows of a wave's block
+        const int m_base = tmi * TM + wr * WRM, n_base = tni * 256 + wc * 128;
         stamp(it, 0);
         ktile(true);
 #pragma unroll 1
@@ -553,27 +602,30 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
             }
         };
         if constexpr (BIAS_EARLY) next_bias();
-        char* slice = smem + Q_EPI + wave * Q_SLICE;
-        const bool full = (m_base + 128 <= p.M) && (n_base + 128 <= p.N);
+        char* slice = smem + NST * BUF + wave * SLICE;
+        const bool full = (m_base + WRM <= p.M) && (n_base + 128 <= p.N);
+        // small launches (HM): the next kernel finds the output in the L2 / MALL -> plain stores
+        constexpr bool NTS = !HM && (VAR & 4096) == 0;
         if constexpr (NO_EPI) {
 #pragma unroll
             for (int nj = 0; nj < 8; ++nj)
 #pragma unroll
-                for (int mi = 0; mi < 8; ++mi) asm volatile("" ::"a"(acc[nj][mi]));
+                for (int mi = 0; mi < NMI; ++mi) asm volatile("" ::"a"(acc[nj][mi]));
         } else if constexpr (EPI == EPI_STORE_F32 || EPI == EPI_GELU_F32 || EPI == EPI_RESID_F32) {
-            if (full) epilogue9_f32<T, EPI, true>(p, acc, m_base, n_base, lane, slice);
-            else epilogue9_f32<T, EPI, false>(p, acc, m_base, n_base, lane, slice);
+            if (full) epilogue9_f32<T, EPI, true, 4, NTS, NMI, HM>(p, acc, m_base, n_base, lane, slice);
+            else epilogue9_f32<T, EPI, false, 4, NTS, NMI, HM>(p, acc, m_base, n_base, lane, slice);
         } else if constexpr (EPI == EPI_V_T) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int nb = n_base + 64 * hf;
-                const bool f2 = (m_base + 128 <= p.M) && (nb + 64 <= p.N) && (p.T % 32 == 0);
-                if (f2) epilogue8m<T, EPI, true, false, false, 4, 8, true>(p, acc, 4 * hf, m_base, nb, lane, slice + hf * 4096, 0, 0, 0);
-                else epilogue8m<T, EPI, false, false, false, 4, 8, true>(p, acc, 4 * hf, m_base, nb, lane, slice + hf * 4096, 0, 0, 0);
+                const bool f2 = (m_base + WRM <= p.M) && (nb + 64 <= p.N) && (p.T % 32 == 0);
+                char* sl2 = slice + (HM ? 0 : hf * 4096);
+                if (f2) epilogue8m<T, EPI, true, false, false, NMI / 2, 8, NTS, NMI>(p, acc, 4 * hf, m_base, nb, lane, sl2, 0, 0, 0);
+                else epilogue8m<T, EPI, false, false, false, NMI / 2, 8, NTS, NMI>(p, acc, 4 * hf, m_base, nb, lane, sl2, 0, 0, 0);
             }
         } else {
-            if (full) epilogue9_t<T, EPI, true, (VAR & 4096) == 0>(p, acc, m_base, n_base, lane, slice);
-            else epilogue9_t<T, EPI, false, (VAR & 4096) == 0>(p, acc, m_base, n_base, lane, slice);
+            if (full) epilogue9_t<T, EPI, true, NTS, NMI, HM ? 16 : 32>(p, acc, m_base, n_base, lane, slice);
+            else epilogue9_t<T, EPI, false, NTS, NMI, HM ? 16 : 32>(p, acc, m_base, n_base, lane, slice);
         }
         if constexpr (!BIAS_EARLY) next_bias();
         stamp(it, 2);
@@ -599,10 +651,10 @@ static int num_workgroups9() {
     return n;
 }
 
-template <typename T, int EPI, int VAR = 0>
+template <typename T, int EPI, int VAR = 0, bool HM = false>
 static hipError_t launch9(GemmArgs p, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = gemm9_kernel<T, EPI, VAR>;
+    auto kern = gemm9_kernel<T, EPI, VAR, HM>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
@@ -623,7 +675,7 @@ static hipError_t launch9(GemmArgs p, hipStream_t st) {
 
 bool gemm9_supports(const GemmArgs& p, int epi) {
     if (p.K % 64 != 0 || p.N % 8 != 0 || p.M <= 0) return false;
-    if (gemm8_generalised(p, epi) || p.half_m > 0) return false;
+    if (gemm8_generalised(p, epi)) return false;
     if ((epi == EPI_QKV_ROPE || epi == EPI_V_T) && p.N % 64 != 0) return false;
     if ((long long)256 * p.K * 2 > 0x7fffffffLL) return false;  // a panel must fit a buffer descriptor
     return epi >= EPI_STORE_T && epi <= EPI_V_T;
@@ -644,6 +696,30 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
     if (var == 2) { ESMK_G9_ALL(2) }  // A/B of the issue patterns in the whole forward (ESMK_GEMM_IMPL=9:2 / 9:3)
     if (var == 3) { ESMK_G9_ALL(3) }
 #undef ESMK_G9_ALL
+    if constexpr (std::is_same<T, _Float16>::value) {
+        if (p.half_m > 0 && epi == EPI_STORE_T) {  // timing experiments on the half-height kernel
+            switch (var) {
+                case 8: return launch9<T, EPI_STORE_T, 8, true>(p, st);
+                case 16: return launch9<T, EPI_STORE_T, 16, true>(p, st);
+                case 32: return launch9<T, EPI_STORE_T, 32, true>(p, st);
+                case 64: return launch9<T, EPI_STORE_T, 64, true>(p, st);
+                case 128: return launch9<T, EPI_STORE_T, 128, true>(p, st);
+                case 96: return launch9<T, EPI_STORE_T, 96, true>(p, st);
+                case 224: return launch9<T, EPI_STORE_T, 224, true>(p, st);
+            }
+        }
+    }
+    if (var == 0 && p.half_m > 0) {  // half-height tiles
+        switch (epi) {
+            case EPI_STORE_T: return launch9<T, EPI_STORE_T, 0, true>(p, st);
+            case EPI_STORE_F32: return launch9<T, EPI_STORE_F32, 0, true>(p, st);
+            case EPI_GELU_T: return launch9<T, EPI_GELU_T, 0, true>(p, st);
+            case EPI_GELU_F32: return launch9<T, EPI_GELU_F32, 0, true>(p, st);
+            case EPI_RESID_F32: return launch9<T, EPI_RESID_F32, 0, true>(p, st);
+            case EPI_QKV_ROPE: return launch9<T, EPI_QKV_ROPE, 0, true>(p, st);
+            case EPI_V_T: return launch9<T, EPI_V_T, 0, true>(p, st);
+        }
+    }
     if (var == 0) {
         switch (epi) {
             case EPI_STORE_T: return launch9<T, EPI_STORE_T>(p, st);

@@ -310,8 +310,8 @@ ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int 
 // NI = number of 32-row pieces of the wave's block: 4 (128 rows), or 2 in the half-height tile mode (HM).
 // NT: the aligned global stores carry the non-temporal policy (large launches: the output is not read again by this
 // launch and should not push the operand panels out of the XCD's L2).
-template <typename T, int EPI, bool FULL, bool NOSTORE = false, bool GEN = false, int NI = 4, int NJT = 4, bool NT = false>
-ESMK_DEV void epilogue8m(const GemmArgs& p, f32x4 (&acc)[NJT][8], int nj0, int m_base, int n_base, int lane,
+template <typename T, int EPI, bool FULL, bool NOSTORE = false, bool GEN = false, int NI = 4, int NJT = 4, bool NT = false, int NMI = 8>
+ESMK_DEV void epilogue8m(const GemmArgs& p, f32x4 (&acc)[NJT][NMI], int nj0, int m_base, int n_base, int lane,
                          char* wl, size_t out_off, int zo, int zi) {
     using V4 = typename Op<T>::v4;
     using V8 = typename Op<T>::v8;

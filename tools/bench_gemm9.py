@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--no-vendor", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--tolerant", action="store_true", help="gemm9 == gemm8 up to the fp32 summation order instead of bit for bit")
+    ap.add_argument("--half", action="store_true", help="time the half-height kernels (small batches) and their experiment variants")
     ap.add_argument("--cases", default="", help="comma-separated substrings of case names to run (default: all)")
     ap.add_argument("--dbg", action="store_true", help="also the timing-experiment variants of gemm9 (plain store only)")
     args = ap.parse_args()
@@ -143,7 +144,14 @@ def main():
         out = torch.zeros(M, N, device="cuda") if epi == nat.EPI_RESID_F32 else None
         flops = 2.0 * M * N * K
         arms = [("gemm8", 8, 0), ("gemm9", 9, 0)]
-        if args.dbg and epi == nat.EPI_STORE_T:
+        hm = 0
+        if args.half:
+            hm = 1
+            arms = [("gemm8 half", 8, 0), ("gemm9 half", 9, 0)]
+            if epi == nat.EPI_STORE_T:
+                arms += [("g9h no-barrier", 9, 8), ("g9h no-mfma", 9, 16), ("g9h no-dma", 9, 32), ("g9h no-reads", 9, 64), ("g9h no-epi", 9, 128),
+                         ("g9h mfma-only", 9, 96), ("g9h skeleton", 9, 224)]
+        if args.dbg and epi == nat.EPI_STORE_T and not args.half:
             arms += [("g9 dense", 9, 1), ("g9 spread24-61", 9, 2), ("g9 24+2k", 9, 3), ("g9 temporal-st", 9, 4096), ("g9 no-barrier", 9, 8),
                      ("g9 no-mfma", 9, 16), ("g9 no-dma", 9, 32), ("g9 no-reads", 9, 64), ("g9 no-epi", 9, 128), ("g9 mfma-only", 9, 96)]
         times = {n: [] for n, _, _ in arms}
@@ -153,13 +161,13 @@ def main():
         for _ in range(args.rounds):
             for n, impl, var in arms:
                 set_impl(impl, var)
-                times[n].append(timeit(lambda: ops.linear(a, w, bias, epi, out=out), args.iters))
+                times[n].append(timeit(lambda: ops.linear(a, w, bias, epi, out=out, half_m=hm), args.iters))
             if "vendor" in times:
                 times["vendor"].append(timeit(lambda: torch.nn.functional.linear(a, w, bias_t), args.iters))
         nt = ((M + 255) // 256) * ((N + 255) // 256)
         for n, impl, var in arms:
             set_impl(impl, var)
-            loop, ep, seam, ghz = stamps(lambda: ops.linear(a, w, bias, epi, out=out), min(32, nt // 256), K // 64)
+            loop, ep, seam, ghz = stamps(lambda: ops.linear(a, w, bias, epi, out=out, half_m=hm), min(32, nt // 256), K // 64)
             ms = statistics.median(times[n])
             print(f"{name:12s} {n:18s} {ms*1e3:8.1f} us (min {min(times[n])*1e3:8.1f}) {flops/ms/1e9:7.1f} TFLOP/s | cycles/K-tile {loop:7.1f} "
                   f"epilogue {ep:7.0f} seam {seam:6.0f} clock {ghz:4.2f} GHz", flush=True)
