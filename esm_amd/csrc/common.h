@@ -1,6 +1,7 @@
 // common.h — shared device helpers for the gfx950 (MI355X / CDNA4) ESM-2 engine.
-// Written for gfx950 only: 64-lane wavefronts, v_mfma_f32_32x32x16_{f16,bf16},
-// global_load_lds_dwordx4, 160 KiB LDS per CU.
+// Written for gfx950 only: 64-lane wavefronts, v_mfma_f32_16x16x32_{f16,bf16} (linear layers: 13 % less energy per flop
+// than the 32x32x16 shape under the package power cap, tools/mfma_power_probe.hip) and v_mfma_f32_32x32x16 (attention,
+// contacts), LDS-DMA (global_load_lds_dwordx4 / buffer_load ... lds), 160 KiB LDS per CU.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

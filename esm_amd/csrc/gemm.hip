@@ -9,8 +9,9 @@
 //   * exact-erf GELU (modules.py:17-24)                                      -> EPI_GELU_*
 //   * residual add into the fp32 stream (modules.py:134,140)                 -> EPI_RESID_F32
 //
-// Fast kernel (gemm256): 256x256 output tile, K step 64, 8 waves (2 along M x 4 along N, each
-// wave 128x64 = 4x2 v_mfma_f32_32x32x16 tiles), operands staged HBM->LDS with
+// One-tile-per-workgroup kernel (gemm256; the reference the persistent kernels are tested against bit for bit):
+// 256x256 output tile, K step 64, 8 waves (2 along M x 4 along N, each
+// wave 128x64 = 8x4 v_mfma_f32_16x16x32 blocks), operands staged HBM->LDS with
 // global_load_lds_dwordx4 into two 64 KiB LDS buffers (one barrier per K step), LDS rows are
 // 128 B with the 16-byte chunk index XOR-swizzled by ((row>>1)&7) so that every ds_read_b128
 // lane group touches 16 distinct 16-byte slots (conflict free).  Because global_load_lds
@@ -22,7 +23,7 @@
 // The MFMA is issued "swapped" (A operand = weight rows, B operand = activation rows) so a
 // lane owns 4 consecutive output columns of one output row: epilogue stores are 8 B (f16/bf16)
 // or 16 B (fp32) per lane, and the RoPE partner (column + 32 of the same head) lives in the
-// same lane and register index of the neighbouring 32-column tile.
+// same lane and register index two 16-column blocks further (epilogues: gemm_epi.h).
 //
 // Generic kernel (gemm64): 64x64 tile, K step 32, register staged with row clamping and
 // per-element predicated stores; used for shapes the fast kernel does not cover

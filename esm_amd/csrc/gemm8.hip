@@ -22,7 +22,7 @@
 //   * PING-PONG: the two waves of a SIMD (wave w of group 0 = rows 0..127, wave w+4 of group 1 =
 //     rows 128..255) run the same instruction stream shifted by one barrier.  A K tile is four
 //     phases; each phase is a load section (ds_reads of the next fragments + 2 LDS-DMA
-//     instructions + a COUNTED s_waitcnt vmcnt(8)) and a matrix section (8 v_mfma_f32_32x32x16 =
+//     instructions + a COUNTED s_waitcnt vmcnt(8)) and a matrix section (16 v_mfma_f32_16x16x32 =
 //     one 64x32 quadrant of the wave's 128x64 block over K = 64), separated by raw s_barrier.
 //     While one group issues MFMAs the other one issues its LDS / DMA traffic.
 //   * vmcnt is never drained in the loop: a unit is waited for 4 load sections (= 8 DMA

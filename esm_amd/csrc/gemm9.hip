@@ -2,27 +2,35 @@
 //     C[M,N] = A[M,K] . W[N,K]^T (+ bias, + fused epilogue)          K % 64 == 0, N % 8 == 0, dense operands
 //
 // Same contract, tile order and results as gemm8.hip (reference esm/multihead_attention.py:256-261,395;
-// esm/modules.py:138-139), different main loop.  gemm8 runs 8 waves (two per SIMD) on 128 x 64 wave blocks and
-// hides LDS / DMA latency by ping-pong between the two waves of a SIMD: 8 barriers per K tile, 24 KiB of fragment
-// reads per 32 MFMAs.  gemm9 runs 4 waves (one per SIMD, 256 accumulator + 256 vector registers each) on 128 x 128
-// wave blocks of the same 256 x 256 x 64 tile:
-//   * fragment reads per MFMA drop by a third (32 KiB per 64 MFMAs per wave);
-//   * the wave's own instruction stream interleaves its 64 MFMAs with 32 ds_read_b128 and 16 LDS-DMA pieces, every
-//     MFMA gap carrying at most one read and one piece (pinned with sched_barrier: hipcc's own interleave bunches them);
-//   * TWO barriers per K tile, the LDS-DMA queue is never drained (counted vmcnt), a piece has 62 - 92 MFMA slots
-//     (> 1 K tile) to land.
+// esm/modules.py:138-139), different main loop; since round 3 the kernel of every dense launch of the layer stack
+// (gemm8 keeps the generalised-addressing calls: MSA Transformer, split weights, packed batches).  gemm8 runs 8 waves
+// (two per SIMD) on 128 x 64 wave blocks and hides LDS / DMA latency by ping-pong between the two waves of a SIMD:
+// 8 barriers per K tile, 24 KiB of fragment reads per 256 cycles of MFMA.  gemm9 runs 4 waves (one per SIMD, 256
+// accumulator + 256 vector registers each) on 128 x 128 wave blocks of the same 256 x 256 x 64 tile:
+//   * fragment reads per MFMA drop by a third (32 KiB per 2048 cycles of MFMA per wave);
+//   * the wave's own instruction stream interleaves its 128 v_mfma_f32_16x16x32 (64 slots of two) with 32 ds_read_b128
+//     and 16 LDS-DMA pieces, pinned with sched_barrier (hipcc's own interleave bunches them);
+//   * TWO barriers per K tile, the LDS-DMA queue is never drained (counted vmcnt), a piece has > 1 K tile to land.
 // Every output element sees the same MFMA sequence over K as in gemm8 (bias enters as the C operand of the first
 // MFMA, then K ascending), so results are bit-identical to gemm8's (tools/bench_gemm9.py checks it on ragged shapes).
 //
-// What was measured on the way (profiles/r3_gemm9_v1_*.log, one box, M = 65536): a first version with one barrier per
-// K tile and `vmcnt(0)` before it ran 3300 - 3500 cycles per K tile against gemm8's 2650 although its fragment reads
-// cost nothing (2200 cycles without the DMA): the 64 KiB of LDS-DMA per K tile and CU need ~1.6 us under full-chip load
-// whatever issues them, so a queue that is drained once per K tile idles half of the time.  Staging through registers
-// (global_load -> 64 VGPRs three positions ahead -> ds_write_b128) did not help (the ds_writes alone cost 340 cycles
-// per K tile).  The schedule below is the vendor asm kernel's idea (hipBLASLt MT256x256x64, one wave per SIMD, read
-// with llvm-objdump): hold the fragments of a WHOLE K tile in registers (128 VGPRs), read them early, so that the
-// LDS buffer of K tile s is free again a third into K tile s and the DMA of K tile s+2 streams into it while the
-// wait for K tile s+1 leaves the youngest pieces in flight.
+// What was measured on the way (profiles/r3_gemm9_*.log, M = 65536):
+//   * v1: one barrier per K tile and `vmcnt(0)` before it: 3300 - 3500 cycles per K tile against gemm8's 2650 although
+//     its fragment reads cost nothing (2200 cycles without the DMA) — a queue drained once per K tile idles half of the
+//     time.  Staging through registers (global_load -> VGPRs -> ds_write_b128) did not help.
+//   * schedule C (the vendor asm kernel's idea, hipBLASLt MT256x256x64_MI16x16x1, read with llvm-objdump): the
+//     fragments of a WHOLE K tile live in registers (128 VGPRs) and are read early, so that the LDS buffer of K tile s
+//     is free again a quarter into K tile s and the DMA of K tile s+2 streams into it: ties gemm8 (both on the 1400 W
+//     cap at 1.6 GHz).
+//   * 16x16x32 MFMAs instead of 32x32x16 (tools/mfma_power_probe.hip: 13 % less energy per flop — the shape the vendor
+//     kernel uses): the clock rises to 1.8 - 1.9 GHz and the loop becomes DMA bound.
+//   * a piece that finds the CU's memory pipeline busy stalls the wave — and with one wave per SIMD its MFMA issue;
+//     4 waves x 1 piece per 2 slots is the pipeline's peak rate.  One piece per 3 slots: +8 .. 9 %.
+//   * non-temporal output stores (the output tile is not read again by the launch and was pushing operand panels out
+//     of the XCD's L2): +4 .. 7 % on the K = 1280 shapes.  Together: 1140 - 1270 TFLOP/s on the four layer shapes,
+//     the hipBLASLt kernel's rate (same box: 1194 - 1284), gemm8 1060 - 1125.
+//   * K offset staggered by tile column (the vendor's StaggerU): the DMA stream alone +12 %, the kernel +-0; operand
+//     loads with nt / sc bits: worse (tools/dma_probe.hip: the stream alone runs 22.5 TB/s, L2-resident data 32 TB/s).
 //
 // LDS (160 KiB): two K-tile buffers of 64 KiB (A rows 0..255, then W rows 0..255; 128-byte rows, 16-byte chunk index
 // XOR-swizzled with (row >> 1) & 7 on the DMA source address and on the ds_read_b128), then 4 x 8 KiB wave-private
@@ -30,16 +38,16 @@
 // `buffer_load ... lds`: rows past the end of the operand are out of the descriptor's range and arrive as zeros);
 // wave (wr, wc) = (w >> 1, w & 1) computes rows [128 wr, +128) x columns [128 wc, +128) of the tile.
 //
-// One K tile (stream position s, LDS buffer cur = s & 1), MFMA slots m = 0..63 (m = 32 half + 16 ks + 4 j + i;
-// X = fragments of K 0..31, Y = fragments of K 32..63 of the tile):
+// One K tile (stream position s, LDS buffer cur = s & 1), MFMA slots m = 0..63 (two MFMAs each: K half m >> 5, blocks
+// 2 (m & 31), 2 (m & 31) + 1 of the half's 8 x 8; X = fragments of K 0..31, Y = fragments of K 32..63 of the tile):
 //     m  0..15   ds_read: Y fragments of position s (buffer cur) — X of position s was read during position s-1
-//     m 24       s_waitcnt lgkmcnt(0); s_barrier        every wave has read buffer cur completely
-//     m 24..54   LDS-DMA: the 16 pieces of position s+2 -> buffer cur, one every other slot
-//     m 52       s_waitcnt vmcnt(14); s_barrier         every wave's pieces of position s+1 have landed (the 14
+//     m 16       s_waitcnt lgkmcnt(0); s_barrier        every wave has read buffer cur completely
+//     m 16..61   LDS-DMA: the 16 pieces of position s+2 -> buffer cur, one per three slots
+//     m 52       s_waitcnt vmcnt(12); s_barrier         every wave's pieces of position s+1 have landed (the 12
 //                                                       youngest pieces, of position s+2, stay in flight)
 //     m 52..59   ds_read: X fragments of position s+1 (buffer cur^1), two per slot
 // The K tiles of all tiles of a workgroup form one stream, as in gemm8: the first operands of the next tile land
-// during the epilogue.
+// during the epilogue.  Half-height tiles (small batches): see the HM parameter of the kernel.
 #include "gemm_epi.h"
 #include <stdlib.h>
 #include <string.h>
@@ -330,7 +338,12 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int nk = p.K >> 6;
-    const unsigned rb = (unsigned)p.K * 2u;  // operand row stride in bytes
+    // operand row strides in bytes.  Split weights (f16x2 precision mode, engine.hip): W is the [N, 2 K0] hi | lo image
+    // (p.K = 2 K0), the activations keep K0 columns (a_row_bytes) and every activation K tile meets two weight K tiles
+    // (a_kt_repeat): the activation K offset advances every other stream position.
+    const unsigned rb = (unsigned)p.K * 2u;
+    const unsigned rb_a = p.a_row_bytes ? (unsigned)p.a_row_bytes : rb;
+    const bool a_rep = p.a_kt_repeat != 0;
 
     // ---- static persistent schedule (gemm8's: XCD-contiguous ranges of a column-panel blocked tile order) ----
     const int tiles_m = (p.M + TM - 1) / TM, tiles_n = (p.N + 255) >> 8;
@@ -363,16 +376,16 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     };
     __amdgpu_buffer_rsrc_t d_a, d_w;
     int s_kt, s_it;
-    unsigned s_koff;
-    const unsigned rb8 = 8u * rb;
+    unsigned s_koff, s_koff_a;
+    const unsigned rb8 = 8u * rb, rb8_a = 8u * rb_a;
     // (row >> 1) & 7 of row = 64 wave + 8 q + lane / 8:  4 (q & 1) + ((lane >> 4) & 3)
     // (HM: the wave stages activation rows [32 wave, + 32) — the same swizzle term — and weight rows [64 wave, + 64))
     const unsigned vo_base = (unsigned)(64 * wave + (lane >> 3)) * rb;
     const unsigned vo_even = vo_base + (unsigned)(((lane & 7) ^ ((lane >> 4) & 3)) << 4);
     const unsigned vo_odd = vo_base + (unsigned)(((lane & 7) ^ (4 + ((lane >> 4) & 3))) << 4);
-    const unsigned va_base = (unsigned)(32 * wave + (lane >> 3)) * rb;
-    const unsigned va_even = HM ? va_base + (unsigned)(((lane & 7) ^ ((lane >> 4) & 3)) << 4) : vo_even;
-    const unsigned va_odd = HM ? va_base + (unsigned)(((lane & 7) ^ (4 + ((lane >> 4) & 3))) << 4) : vo_odd;
+    const unsigned va_base = (unsigned)((HM ? 32 : 64) * wave + (lane >> 3)) * rb_a;
+    const unsigned va_even = va_base + (unsigned)(((lane & 7) ^ ((lane >> 4) & 3)) << 4);
+    const unsigned va_odd = va_base + (unsigned)(((lane & 7) ^ (4 + ((lane >> 4) & 3))) << 4);
     auto set_tile = [&](int it) ESMK_INL {
         int tmi, tni;
         tile_coords(it, tmi, tni);
@@ -381,9 +394,10 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
         if constexpr (KSTAG == 1) s_koff = (unsigned)(((blockIdx.x >> 3) & 3) * (nk >> 2)) * 128u;
         else if constexpr (KSTAG == 2) s_koff = (unsigned)((tni & 3) * (nk >> 2)) * 128u;
         else s_koff = 0;
+        s_koff_a = a_rep ? 0u : s_koff;
         const unsigned rows_a = (unsigned)min(TM, p.M - tmi * TM), rows_w = (unsigned)min(256, p.N - tni * 256);
-        d_a = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(reinterpret_cast<const char*>(p.A) + (size_t)tmi * TM * rb), 0,
-                                                (int)__builtin_amdgcn_readfirstlane(rows_a * rb), 0x00020000);
+        d_a = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(reinterpret_cast<const char*>(p.A) + (size_t)tmi * TM * rb_a), 0,
+                                                (int)__builtin_amdgcn_readfirstlane(rows_a * rb_a), 0x00020000);
         d_w = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(reinterpret_cast<const char*>(p.W) + (size_t)tni * 256 * rb), 0,
                                                 (int)__builtin_amdgcn_readfirstlane(rows_w * rb), 0x00020000);
     };
@@ -395,6 +409,7 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
             s_koff += 128u;
             if constexpr (KSTAG != 0)
                 if (s_koff == (unsigned)nk * 128u) s_koff = 0;
+            s_koff_a = a_rep ? (unsigned)(s_kt >> 1) * 128u : s_koff;
         } else if (s_it + 1 < n_my) {
             set_tile(s_it + 1);
         }
@@ -410,7 +425,7 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
             char* dst = smem + buf * BUF + (isw ? WOFF + wave * 8192 : wave * (HM ? 4096 : 8192)) + q * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(isw ? d_w : d_a, (lds_ptr)dst, 16,
                                                      isw ? ((q & 1) ? vo_odd : vo_even) : ((q & 1) ? va_odd : va_even),
-                                                     s_koff + (unsigned)q * rb8, 0, DMA_AUX);
+                                                     isw ? s_koff + (unsigned)q * rb8 : s_koff_a + (unsigned)q * rb8_a, 0, DMA_AUX);
         }
     };
 
@@ -675,7 +690,11 @@ static hipError_t launch9(GemmArgs p, hipStream_t st) {
 
 bool gemm9_supports(const GemmArgs& p, int epi) {
     if (p.K % 64 != 0 || p.N % 8 != 0 || p.M <= 0) return false;
-    if (gemm8_generalised(p, epi)) return false;
+    // of the generalised addressing only the split-weight form (own activation row stride, repeated activation K tiles)
+    if (p.w_row_bytes || p.a_kt_bytes || p.w_kt_bytes || p.batch > 1 || p.n_valid > 0 || p.ldc > 0 || p.row_keep != nullptr ||
+        p.vt_rows > 0 || p.rowmap_R > 0 || epi == EPI_MSA_CTX || p.head_dim != 64 || p.row_pos != nullptr)
+        return false;
+    if (p.a_row_bytes && (p.a_row_bytes % 16 != 0)) return false;
     if ((epi == EPI_QKV_ROPE || epi == EPI_V_T) && p.N % 64 != 0) return false;
     if ((long long)256 * p.K * 2 > 0x7fffffffLL) return false;  // a panel must fit a buffer descriptor
     return epi >= EPI_STORE_T && epi <= EPI_V_T;

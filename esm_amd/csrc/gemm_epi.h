@@ -1,4 +1,4 @@
-// gemm_epi.h — shared by the persistent GEMM kernels (gemm8.hip, gemm9.hip): LDS geometry, barrier / wait helpers and the
+// gemm_epi.h — shared by the GEMM kernels (gemm8.hip, gemm9.hip, gemm.hip): LDS geometry, barrier / wait helpers and the
 // fused epilogues of a wave's 128 x 64 block (bias, q scale + RoPE + head-major store, V^T store, GELU, fp32 residual
 // read-modify-write; reference esm/multihead_attention.py:256-284,395, esm/rotary_embedding.py:11-20, esm/modules.py:17-24,134-140).
 #pragma once
@@ -55,249 +55,9 @@ ESMK_DEV typename Op<T>::v4 pack4_(float a, float b, float c, float d) {
 }
 
 // --------------------------------------------------------------------------------------------
-// epilogue: the wave's 128 (m) x 64 (n) block leaves through a private 4 KiB LDS slice in
-// 32-row pieces, so that every global store instruction covers whole 128-byte row segments.
-//   normal orientation (MFMA A operand = weight rows):
-//     acc[j][i][r]:  m = m_base + 32 i + (lane & 31);  n = n_base + 32 j + 8 (r>>2) + 4 (lane>>5) + (r&3)
-//   EPI_V_T (MFMA A operand = activation rows):
-//     acc[j][i][r]:  n = n_base + 32 j + (lane & 31);  m = m_base + 32 i + 8 (r>>2) + 4 (lane>>5) + (r&3)
-// --------------------------------------------------------------------------------------------
-// The bias is already in the accumulators (gemm8_kernel starts every tile from acc = bias) except for
-// EPI_V_T, whose bias varies with the lane instead of the register.  FULL = the wave's block lies
-// completely inside [0,M) x [0,N): no store is predicated, so the wave issues exactly
-// epilogue_stores<EPI>() store instructions.
-// NI = number of 32-row pieces of the wave's block: 4 (128 rows), or 2 in the half-height tile mode (HM).
-template <typename T, int EPI, bool FULL, bool NOSTORE = false, bool GEN = false, int NI = 4>
-ESMK_DEV void epilogue8(const GemmArgs& p, f32x16 (&acc)[2][4], int m_base, int n_base, int lane,
-                        char* wl, size_t out_off, int zo, int zi) {
-    using V4 = typename Op<T>::v4;
-    using V8 = typename Op<T>::v8;
-    const int h = lane >> 5, lm = lane & 31;
-    if constexpr (!FULL)
-        if (n_base >= p.N || m_base >= p.M) return;  // wave uniform
-
-    if constexpr (EPI == EPI_V_T) {
-        // vt[b][head][dv][Tp], keys permuted inside groups of 16 (4-groups 1 and 2 swapped)
-        const int hd = GEN ? p.head_dim : 64;   // 128: the wave's 64 columns are one half of a head
-        const int head = n_base / hd;
-        const int dv0 = n_base - head * hd;
-        T* vt = reinterpret_cast<T*>(p.vt);
-        const float bv0 = p.bias[n_base + lm], bv1 = p.bias[n_base + 32 + lm];
-        const bool aligned = FULL || (p.T % 32 == 0);  // a 32-token piece = one aligned run of one sequence
-        const bool perm = !GEN || (p.vt_rows == 0);  // ESM-2 attention consumes permuted keys, the MSA context GEMM plain ones
-        // row index of vt for sequence `sq`: ESM-2 [B,H,64,Tp]; MSA row attention [B,H,R,64,Tp], sq = (b,r)
-        auto vt_row0 = [&](int sq) -> size_t {
-            if (!GEN || p.vt_rows == 0) return (size_t)(sq * p.H + head) * hd + dv0;
-            const int bm = sq / p.vt_rows, r = sq - bm * p.vt_rows;
-            return ((size_t)(bm * p.H + head) * p.vt_rows + r) * 64;
-        };
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            // LDS piece: 64 rows (dv) x 64 B (32 tokens); 16-byte chunk c holds 8 token slots
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int dv = 32 * j + lm;
-                const float bv = j ? bv1 : bv0;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    // tokens 8g + 4h + e (e = 0..3) of the piece
-                    const int chunk = (aligned && perm) ? 2 * (g >> 1) + h : g;
-                    const int half = (aligned && perm) ? (g & 1) : h;
-                    *reinterpret_cast<V4*>(wl + dv * 64 + ((chunk ^ ((dv >> 1) & 3)) << 4) + 8 * half) =
-                        pack4_<T>(acc[j][i][4 * g] + bv, acc[j][i][4 * g + 1] + bv,
-                                  acc[j][i][4 * g + 2] + bv, acc[j][i][4 * g + 3] + bv);
-                }
-            }
-            const int mp = m_base + 32 * i;
-            if (aligned) {
-                if (FULL || mp < p.M) {
-                    const int b = mp / p.T, t0 = mp - b * p.T;
-                    T* base = vt + vt_row0(b) * p.Tp + t0;
-                    V8 v[4];
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        const int pc = it * 64 + lane;
-                        const int r = pc >> 2, c = pc & 3;
-                        v[it] = *reinterpret_cast<const V8*>(wl + r * 64 + ((c ^ ((r >> 1) & 3)) << 4));
-                    }
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        const int pc = it * 64 + lane;
-                        const int r = pc >> 2, c = pc & 3;
-                        *reinterpret_cast<V8*>(base + (size_t)r * p.Tp + c * 8) = v[it];
-                    }
-                }
-            } else {
-                // any T: per-element stores, the key permutation applied per token
-#pragma unroll 1
-                for (int idx = lane; idx < 64 * 32; idx += 64) {
-                    const int r = idx >> 5, tl = idx & 31;
-                    const int m = mp + tl;
-                    if (m >= p.M) continue;
-                    const T v = *reinterpret_cast<const T*>(wl + r * 64 + (((tl >> 3) ^ ((r >> 1) & 3)) << 4) +
-                                                            2 * (tl & 7));
-                    const int b = m / p.T, t = m - b * p.T;
-                    const int t16 = t & 15;
-                    const int tp = perm ? ((t & ~15) | ((((t16 >> 2) & 1) << 3) | (((t16 >> 3) & 1) << 2) | (t16 & 3))) : t;
-                    vt[(vt_row0(b) + r) * (size_t)p.Tp + tp] = v;
-                }
-            }
-        }
-    } else if constexpr (EPI == EPI_QKV_ROPE) {
-        // q and k projections (N = 2E): the wave's 64 columns are exactly one head (head_dim 64)
-        const int which = n_base / p.E;  // 0 q, 1 k (wave uniform)
-        // head_dim 128: a head is two 64-column slices; the weights are packed so that slice sl holds dims
-        // [32 sl, 32 sl + 32) and their rotary partners 64 further up, i.e. the partner of column c is c + 32
-        const int hd = GEN ? p.head_dim : 64;
-        const int hrem = n_base - which * p.E;
-        const int head = hrem / hd;
-        const int sl = (hrem - head * hd) >> 6;
-        const int rope_ld = hd >> 1;
-        T* qk = reinterpret_cast<T*>(which == 0 ? p.q : p.k);
-        const float sc = which == 0 ? p.scaling : 1.0f;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int m = min(m_base + 32 * i + lm, p.M - 1);
-            const int t = (GEN && p.row_pos != nullptr) ? p.row_pos[m] : m % p.T;
-            // MSA row attention zeroes q at padded positions (axial_attention.py:85-88)
-            const float keep = (GEN && which == 0 && p.row_keep != nullptr) ? p.row_keep[m] : 1.0f;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = 8 * g + 4 * h;  // first of 4 consecutive dims in [0,32)
-                const f32x4 c = *reinterpret_cast<const f32x4*>(p.cos + (size_t)t * rope_ld + sl * 32 + d0);
-                const f32x4 s = *reinterpret_cast<const f32x4*>(p.sin + (size_t)t * rope_ld + sl * 32 + d0);
-                float y1[4], y2[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    // bias, q scaling (mha.py:261), x*cos + rotate_half(x)*sin (rotary_embedding.py:11-20)
-                    const float a1 = acc[0][i][4 * g + e] * (sc * keep);
-                    const float a2 = acc[1][i][4 * g + e] * (sc * keep);
-                    y1[e] = a1 * c[e] - a2 * s[e];
-                    y2[e] = a2 * c[e] + a1 * s[e];
-                }
-                *reinterpret_cast<V4*>(wl + lm * 128 + ((g ^ (lm & 7)) << 4) + 8 * h) =
-                    pack4_<T>(y1[0], y1[1], y1[2], y1[3]);
-                *reinterpret_cast<V4*>(wl + lm * 128 + (((4 + g) ^ (lm & 7)) << 4) + 8 * h) =
-                    pack4_<T>(y2[0], y2[1], y2[2], y2[3]);
-            }
-            V8 v[4];  // all LDS reads first, then the stores
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int pc = it * 64 + lane;
-                const int r = pc >> 3, cc = pc & 7;
-                v[it] = *reinterpret_cast<const V8*>(wl + r * 128 + ((cc ^ (r & 7)) << 4));
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int pc = it * 64 + lane;
-                const int r = pc >> 3, cc = pc & 7;
-                const int mm = m_base + 32 * i + r;
-                if (FULL || mm < p.M) {
-                    const int b = mm / p.T, tt = mm - b * p.T;
-                    *reinterpret_cast<V8*>(qk + ((size_t)(b * p.H + head) * p.T + tt) * hd + sl * 64 + cc * 8) = v[it];
-                }
-            }
-        }
-    } else if constexpr (EPI == EPI_STORE_T || EPI == EPI_GELU_T || EPI == EPI_MSA_CTX) {
-        T* out = reinterpret_cast<T*>(reinterpret_cast<char*>(p.out) + out_off);
-        const int ldc = (GEN && p.ldc > 0) ? p.ldc : p.N;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
-                    if constexpr (EPI == EPI_GELU_T) gelu_fast_x4(v);
-                    *reinterpret_cast<V4*>(wl + lm * 128 + (((4 * j + g) ^ (lm & 7)) << 4) + 8 * h) =
-                        pack4_<T>(v[0], v[1], v[2], v[3]);
-                }
-            V8 v[4];  // all LDS reads first, then the stores
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int pc = it * 64 + lane;
-                const int r = pc >> 3, cc = pc & 7;
-                v[it] = *reinterpret_cast<const V8*>(wl + r * 128 + ((cc ^ (r & 7)) << 4));
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int pc = it * 64 + lane;
-                const int r = pc >> 3, cc = pc & 7;
-                const int m = m_base + 32 * i + r, n = n_base + cc * 8;
-                if constexpr (NOSTORE) {
-                    asm volatile("" ::"v"(v[it]));
-                } else if constexpr (EPI == EPI_MSA_CTX) {
-                    // rows m = query column i, the wave's 64 columns = one MSA row r = n_base / 64:
-                    // ctx[((zo*R + r)*C + m)*ldc + zi*64 + (n - n_base)]   (axial_attention.py:111-112)
-                    if (FULL || (m < p.M && n < p.N))
-                        *reinterpret_cast<V8*>(out + ((size_t)(zo * p.ctx_R + (n_base >> 6)) * p.ctx_C + m) * ldc +
-                                               zi * 64 + cc * 8) = v[it];
-                } else if (FULL || (m < p.M && n < p.N)) {
-                    *reinterpret_cast<V8*>(out + (size_t)m * ldc + n) = v[it];
-                }
-            }
-        }
-    } else {
-        // fp32 outputs: 8 pieces of 32 rows x 32 columns (128-byte row segments)
-        float* out = reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + out_off);
-        const int ldc = (GEN && p.ldc > 0) ? p.ldc : p.N;
-        f32x4 old[4], nxt[4];
-        auto load_old = [&](f32x4 (&dst)[4], int piece) {
-            const int i = piece >> 1, j = piece & 1;
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int pc = it * 64 + lane;
-                const int m = remap_row<GEN>(p, min(m_base + 32 * i + (pc >> 3), p.M - 1));
-                const int n = min(n_base + 32 * j + (pc & 7) * 4, p.N - 4);
-                dst[it] = *reinterpret_cast<const f32x4*>(out + (size_t)m * ldc + n);
-            }
-        };
-        if constexpr (EPI == EPI_RESID_F32) load_old(old, 0);
-#pragma unroll
-        for (int piece = 0; piece < 2 * NI; ++piece) {
-            const int i = piece >> 1, j = piece & 1;
-            if constexpr (EPI == EPI_RESID_F32)
-                if (piece + 1 < 2 * NI) load_old(nxt, piece + 1);  // residual of the next piece in flight
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
-                if constexpr (EPI == EPI_GELU_F32) gelu_fast_x4(v);
-                *reinterpret_cast<f32x4*>(wl + lm * 128 + (((2 * g + h) ^ (lm & 7)) << 4)) = v;
-            }
-            f32x4 vv[4];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int pc = it * 64 + lane;
-                const int r = pc >> 3, cc = pc & 7;
-                vv[it] = *reinterpret_cast<const f32x4*>(wl + r * 128 + ((cc ^ (r & 7)) << 4));
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int pc = it * 64 + lane;
-                const int r = pc >> 3, cc = pc & 7;
-                f32x4 v = vv[it];
-                if constexpr (EPI == EPI_RESID_F32)
-                    v = f32x4{old[it][0] + v[0], old[it][1] + v[1], old[it][2] + v[2], old[it][3] + v[3]};
-                const int m = m_base + 32 * i + r, n = n_base + 32 * j + cc * 4;
-                if (FULL || (m < p.M && n < p.N))
-                    *reinterpret_cast<f32x4*>(out + (size_t)(EPI == EPI_RESID_F32 ? remap_row<GEN>(p, m) : m) * ldc + n) = v;
-            }
-            if constexpr (EPI == EPI_RESID_F32) {
-#pragma unroll
-                for (int it = 0; it < 4; ++it) old[it] = nxt[it];
-            }
-        }
-    }
-}
-
-// --------------------------------------------------------------------------------------------
-// epilogue8m: the same epilogues on 16 x 16 x 32 MFMA accumulators (acc[nj][mi]: 16-column block nj0 + nj of the
-// wave's 64 columns, 16-row block mi of its 128 rows; four registers each).  The LDS piece images and everything
-// behind them (row-major reads, global stores) are those of epilogue8; only the lane -> (row, column) map differs:
+// epilogue8m: the wave's 128 (m) x 64 (n) block leaves through a private 4 KiB LDS slice in 32-row pieces, so that
+// every global store instruction covers whole 128-byte row segments.  Accumulators of 16 x 16 x 32 MFMAs: acc[nj][mi] =
+// 16-column block nj0 + nj of the wave's 64 columns x 16-row block mi of its rows, four registers each:
 //   normal orientation (MFMA first operand = weight rows):
 //     acc[nj][mi][r]:  m = m_base + 16 mi + (lane & 15);  n = n_base + 16 nj + 4 (lane >> 4) + r
 //   EPI_V_T (MFMA first operand = activation rows):
