@@ -375,7 +375,7 @@ def operand_floor_report(sd, toks_cpu, L, H, r_ref):
 # time limit; nothing in here can cost the flagship line.
 SECONDARY = [  # --quick-baseline: the children's own CPU-oracle sample (parity + cpu_baseline), sized for a few seconds
     ("msa1b", ["--workload", "msa1b", "--quick-baseline"], 120),
-    ("extract_650m", ["--workload", "extract_650m", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"], 150),
+    ("extract_650m", ["--workload", "extract_650m", "--steps", "8", "--warmup", "2", "--quick-baseline"], 150),
     ("esm2_3b_contacts", ["--workload", "esm2_3b_contacts", "--steps", "4", "--quick-baseline"], 200),
 ]
 T_PROCESS_START = time.perf_counter()
@@ -604,6 +604,34 @@ def run_extract_650m(args, dist, rank, world, dev):
             elapsed = float(t.item())
         n_files = sum(1 for _ in out_dir.rglob("*.pt"))
         nbytes = sum(p.stat().st_size for p in out_dir.rglob("*.pt"))
+        check = None
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            # parity of what was WRITTEN: one result file of the timed run read back and compared with the CPU oracle on
+            # that sequence (a bounded sample: one L = 1022 forward, ~2 s on 32 threads); its timing is the CPU baseline
+            try:
+                from oracle.esm2_oracle import esm2_forward
+
+                ncores = cpu_threads()
+                label, seq = timed[0]
+                rec = torch.load(out_dir / f"{label}.pt")
+                _, _, toks1 = alphabet.get_batch_converter()([(label, seq)])
+                sd = {k: v.float().cpu() for k, v in model.state_dict().items()}
+                esm2_forward(sd, toks1[:, :64], L, H, repr_layers=[L])  # warm-up of the thread pool
+                c0 = time.perf_counter()
+                ref = esm2_forward(sd, toks1, L, H, repr_layers=[L])["representations"][L][0, 1:len(seq) + 1].double()
+                dt = time.perf_counter() - c0
+                got = rec["representations"][L].double()
+                gm = rec["mean_representations"][L].double()
+                check = ({"rel_repr_diff_vs_cpu": ((got - ref).abs().max() / ref.abs().max()).item(),
+                          "rel_l2_repr_diff_vs_cpu": ((got - ref).norm() / ref.norm()).item(),
+                          "mean_repr_rel_diff_vs_cpu": ((gm - ref.mean(0)).abs().max() / ref.mean(0).abs().max()).item(),
+                          "what": f"result file {label}.pt of the timed run read back (representations[{L}] [{len(seq)}, {E}] and "
+                                  "its mean) against the fp32 CPU oracle on the same sequence"},
+                         {"value": round(len(seq) / dt, 1), "unit": "residues/s", "cores": ncores, "host_cores": os.cpu_count(),
+                          "kind": "port", "sample": f"fp32 oracle on {ncores} threads, one sequence of the timed FASTA "
+                                                    f"(L = {len(seq)}), one forward after a short warm-up"})
+            except Exception as e:  # reported, never raised
+                check = ({"error": f"{type(e).__name__}: {e}"[:200]}, None)
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
     value = world * batch * args.seq_len * args.steps / elapsed
@@ -620,6 +648,10 @@ def run_extract_650m(args, dist, rank, world, dev):
     result["e2e_mfma_frac_per_gpu"] = round(value / world * 1.4769e9 / (MFMA_PEAK_TFLOPS * 1e12), 4)
     result["roofline"] = None   # a host + PCIe + file-system pipeline: the forward's roofline is the esm2_650m line
     result["library"] = library_build()
+    if check is not None:
+        result["parity"], cb = check
+        if cb is not None:
+            result["cpu_baseline"] = cb
     return result
 
 

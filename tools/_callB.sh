@@ -1,7 +1,11 @@
 O=gpurun_out/r3B
 mkdir -p $O
-timeout 900 python -m pytest tests/test_f16x2_gpu.py tests/test_kernels_gpu.py tests/test_round3_gpu.py -q -x 2>&1 | tail -4
-run() { tag=$1; shift; timeout 300 python bench.py --no-cpu-baseline "$@" > $O/x2_$tag.log 2>&1; python -c "import json; r=json.loads([l for l in open('$O/x2_$tag.log') if l.startswith('{')][-1]); print('$tag', r['value'], r['ms_per_step'], {k: v['ms_per_step'] for k, v in r['kernel_classes'].items() if v['ms_per_step'] > 0.5})"; }
-ESMK_GEMM_IMPL=8 run f16x2_gemm8 --operand f16x2
-run f16x2_gemm9 --operand f16x2
-run f16_650m
+timeout 300 python bench.py --workload extract_650m --steps 8 --warmup 2 --quick-baseline > $O/extract_parity.log 2>&1; python -c "import json; r=json.loads([l for l in open('$O/extract_parity.log') if l.startswith('{')][-1]); print(r['value'], r.get('parity'), r.get('cpu_baseline'))" || tail -5 $O/extract_parity.log
+T0=$(date +%s); timeout 400 python bench.py > $O/default_run.log 2>&1; echo "default wall $(( $(date +%s) - T0 )) s"
+python - <<'PY'
+import json
+r = json.loads([l for l in open("gpurun_out/r3B/default_run.log") if l.startswith("{")][-1])
+print(r["value"], r["ms_per_step"], r["roofline"]["frac"], r["roofline"]["traffic"], r["roofline"].get("traffic_source"))
+for k, v in r["secondary_workloads"].items():
+    print(k, v.get("value"), v.get("wall_s"), "parity" in v, "cpu_baseline" in v, (v.get("roofline") or {}).get("traffic"), v.get("error"), v.get("skipped"))
+PY

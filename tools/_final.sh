@@ -15,7 +15,7 @@ print("cpu", r.get("cpu_baseline", {}).get("value"))
 for k, v in r.get("secondary_workloads", {}).items():
     print("secondary", k, {kk: v.get(kk) for kk in ("value", "ms_per_step", "wall_s", "error", "skipped")}, "parity" in v, "cpu_baseline" in v, (v.get("roofline") or {}).get("traffic"))
 PY
-for spec in "b4:--batch 4" "b16:--batch 16" "bf16:--operand bf16" "f16x2:--operand f16x2"; do
+for spec in "b1:--batch 1" "b4:--batch 4" "b8:--batch 8" "b16:--batch 16" "b32:--batch 32" "bf16:--operand bf16" "f16x2:--operand f16x2"; do
   tag=${spec%%:*}; a=${spec#*:}
   timeout 300 python bench.py $a --no-secondary > $O/bench_650m_$tag.log 2>&1; grep '^{' $O/bench_650m_$tag.log > $O/bench_650m_$tag.json
   python -c "import json; r=json.load(open('$O/bench_650m_$tag.json')); print('$tag', r['value'], r['ms_per_step'], (r.get('parity') or {}).get('rel_repr_diff_vs_cpu'), (r.get('parity') or {}).get('logits_rel_diff'))"

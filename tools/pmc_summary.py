@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 EPI_CLASS = {"2": "gemm_fc1_gelu", "5": "gemm_qkv_rope(qk)", "6": "gemm_qkv_rope(v)", "3": "lm_head_dense", "1": "lm_head_logits"}
 
 
-HAS_G9_RESID = False  # the profiled run sent the long-K residual GEMM (fc2) to gemm9, the out projection to gemm8
+RESID_KERNELS = set()  # residual-GEMM kernel symbols of the profiled run (gemm8 and / or gemm9, epilogue code 4)
 
 
 def classify(name, nth_epi4):
@@ -28,11 +28,10 @@ def classify(name, nth_epi4):
     if m:
         epi = m.group(2)
         if epi == "4":
-            if m.group(1) == "9":
-                return "gemm_fc2"
-            if HAS_G9_RESID:
-                return "gemm_out_proj"
-            # one kernel for both: out_proj and fc2 alternate in launch order inside every layer
+            fams = {re.search(r"gemm([89])_kernel", k).group(1) for k in RESID_KERNELS}
+            if len(fams) == 2:  # round 3a: fc2 on gemm9, the out projection on gemm8
+                return "gemm_fc2" if m.group(1) == "9" else "gemm_out_proj"
+            # one kernel family for both: out_proj and fc2 alternate in launch order inside every layer
             return "gemm_out_proj" if nth_epi4 % 2 == 0 else "gemm_fc2"
         return EPI_CLASS.get(epi, "gemm_epi" + epi)
     for key, cls in (("attn_fwd", "attention"), ("layernorm_kernel", "layernorm"), ("attn_probs", "attention_probs"),
@@ -50,15 +49,16 @@ def main(out_path, dbs, workload="esm2_650m"):
         order = next((x for x in ("dispatch_id", "start", "id") if x in cols), None)
         q = "select kernel_name, counter_name, value, duration" + (f", {order}" if order else "") + " from counters_collection"
         rows = c.execute(q + (f" order by {order}" if order else "")).fetchall()
-        global HAS_G9_RESID
-        HAS_G9_RESID = any(re.search(r"gemm9_kernelI(?:DF16_|DF16b)Li4E", r[0]) for r in rows)
+        RESID_KERNELS.clear()
+        RESID_KERNELS.update(r[0] for r in rows if re.search(r"gemm[89]_kernelI(?:DF16_|DF16b)Li4E", r[0]))
+        one_family = len({re.search(r"gemm([89])_kernel", k).group(1) for k in RESID_KERNELS}) == 1
         seen = {}  # (dispatch key) -> class: every counter of one dispatch gets the same class
         n4 = defaultdict(int)
         for r in rows:
             name, ctr, val, dur = r[:4]
             key = (r[4] if order else None, name)
             if key not in seen or order is None:
-                is4 = re.search(r"gemm8_kernelI(?:DF16_|DF16b)Li4E", name) is not None and not HAS_G9_RESID
+                is4 = re.search(r"gemm[89]_kernelI(?:DF16_|DF16b)Li4E", name) is not None and one_family
                 seen[key] = classify(name, n4[ctr] if order is None else n4["_"])
                 if is4:
                     n4[ctr if order is None else "_"] += 1
