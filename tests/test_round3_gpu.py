@@ -63,6 +63,57 @@ def test_gemm_kernel_choice_never_changes_a_bit(monkeypatch):
         assert torch.equal(r, outs[0][0]) and torch.equal(lg, outs[0][1])
 
 
+def test_tile_height_and_kernel_never_show_in_a_result():
+    """Small batches run on gemm9's half-height tiles (128 x 256, three K-tile buffers), large ones on full tiles, and
+    the rule that picks the height per launch looks at the row count: a sequence must get the same bits alone (B = 1),
+    in the reference script's default batch (B = 4), in B = 24 (mixed heights inside one forward) — and with every dense
+    GEMM forced onto gemm8, whose half-height mode has its own pipeline."""
+    from esm_amd import _native as N
+
+    L, E, H = 2, 1280, 20
+    model = _small(L, E, H, seed=6)
+    toks = synth_tokens(24, 1022, seed=8).cuda()
+    with torch.no_grad():
+        big = model(toks, repr_layers=[L])
+        outs = {b: model(toks[:b], repr_layers=[L]) for b in (1, 4)}
+        try:
+            N.check(N.lib.esmk_debug_gemm_impl(8, 0))
+            g8 = model(toks[:4], repr_layers=[L])
+        finally:
+            N.check(N.lib.esmk_debug_gemm_impl(0, 0))
+    for b, o in outs.items():
+        assert torch.equal(o["representations"][L], big["representations"][L][:b]), b
+        assert torch.equal(o["logits"], big["logits"][:b]), b
+    assert torch.equal(g8["representations"][L], outs[4]["representations"][L])
+    assert torch.equal(g8["logits"], outs[4]["logits"])
+
+
+def test_split_weight_linear_same_bits_on_both_kernels():
+    """The split-weight GEMM of the f16x2 mode (own activation row stride, every activation K tile met twice) runs on
+    gemm9 since round 3; gemm8's generalised-addressing instantiation must give the same bits, and both the fp32-level
+    accuracy the mode exists for."""
+    from esm_amd import _native as N
+    from esm_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for M, Nn, K in ((4096, 1280, 1280), (65536, 2560, 1280), (1000, 264, 320)):
+        a = torch.randn(M, K, device="cuda", generator=g).half()
+        w = torch.randn(Nn, K, device="cuda", generator=g) / K ** 0.5
+        bias = torch.randn(Nn, device="cuda", generator=g)
+        w2 = ops.split_weight(w)
+        outs = []
+        try:
+            for impl in (8, 9, 0):
+                N.check(N.lib.esmk_debug_gemm_impl(impl, 0))
+                outs.append(ops.linear_split(a, w2, bias, N.EPI_STORE_F32).clone())
+        finally:
+            N.check(N.lib.esmk_debug_gemm_impl(0, 0))
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (M, Nn, K)
+        ref = a.double() @ w.double().t() + bias.double()
+        err = ((outs[0].double() - ref).abs().max() / ref.abs().max()).item()
+        assert err < 5e-6, (M, Nn, K, err)   # fp16 weights alone: 1.4e-4
+
+
 def test_extract_writes_every_sequence_once_with_chunked_writer_jobs(tmp_path):
     """The device path of esm_amd.extract (pinned copies on a side stream, chunk jobs on the writer threads): every
     sequence's file exists exactly once and holds the rows of a plain forward."""

@@ -1,4 +1,4 @@
-# final evidence of round 3 (one gpurun call): tests, smoke, bench lines, rocprofv3 kernel stats + PMC passes
+# final evidence of a round in ONE gpurun call: tests, smoke, bench lines of every workload, vendor calibration, rocprofv3 kernel stats + PMC passes.  usage: gpurun --timeout 3000 -- bash tools/final_evidence.sh ; outputs under gpurun_out/r3final
 O=gpurun_out/r3final
 mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -x -q -s > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log
