@@ -297,3 +297,39 @@ def test_precision_study_tool_floor_is_ordered():
 
     want = esm2_forward(sd, toks, L, H, repr_layers=[L])["representations"][L]
     assert (ref - want).abs().max().item() < 1e-5
+
+
+def test_pmc_summary_tells_the_two_residual_gemms_apart(tmp_path):
+    """tools/pmc_summary.py turns rocprofv3 counter rows into per-class HBM bytes that bench.py reports as
+    `roofline.traffic`.  The out projection and fc2 run the same kernel symbol (residual epilogue): they are told apart
+    by launch order inside a layer (round 3: both on gemm9; round 3a: fc2 on gemm9, out_proj on gemm8)."""
+    import json
+    import sqlite3
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def make(path, names):
+        c = sqlite3.connect(path)
+        c.execute("create table counters_collection (dispatch_id int, kernel_name text, counter_name text, value real, duration real)")
+        for i, (name, fetch) in enumerate(names):
+            c.execute("insert into counters_collection values (?,?,?,?,?)", (i, name, "FETCH_SIZE", fetch, 1000.0 * (i + 1)))
+            c.execute("insert into counters_collection values (?,?,?,?,?)", (i, name, "WRITE_SIZE", 10.0, 1000.0 * (i + 1)))
+        c.commit()
+        c.close()
+
+    g9r = "_ZN4esmk12gemm9_kernelIDF16_Li4ELi0ELb0EEEvNS_8GemmArgsEPy"
+    g8r = "_ZN4esmk12gemm8_kernelIDF16_Li4ELi0ELi0ELi0ELb0ELb0EEEvNS_8GemmArgsEPy"
+    g9g = "_ZN4esmk12gemm9_kernelIDF16_Li2ELi0ELb0EEEvNS_8GemmArgsEPy"
+    for tag, layer, want in (("same", [(g9r, 100.0), (g9g, 7.0), (g9r, 300.0)], (100.0, 300.0)),
+                             ("split", [(g8r, 100.0), (g9g, 7.0), (g9r, 300.0)], (100.0, 300.0))):
+        db, out = tmp_path / f"{tag}.db", tmp_path / f"{tag}.json"
+        make(db, layer * 3)
+        subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), str(out), str(db)], check=True,
+                       capture_output=True)
+        k = json.load(open(out))["kernels"]
+        # (launches_profiled counts counter rows: 3 launches x the two counters of this synthetic pass)
+        assert k["gemm_out_proj"]["launches_profiled"] == 6 and k["gemm_fc2"]["launches_profiled"] == 6, tag
+        assert k["gemm_out_proj"]["fetch_kib"] == want[0] and k["gemm_fc2"]["fetch_kib"] == want[1], tag
+        assert k["gemm_fc1_gelu"]["fetch_kib"] == 7.0
