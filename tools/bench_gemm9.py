@@ -134,7 +134,7 @@ def main():
     dt = torch.float16
     cases = [("qk store", 2 * E, E, nat.EPI_STORE_T), ("v/out store", E, E, nat.EPI_STORE_T), ("out resid", E, E, nat.EPI_RESID_F32),
              ("fc1 store", F, E, nat.EPI_STORE_T), ("fc1 gelu", F, E, nat.EPI_GELU_T), ("fc2 store", E, F, nat.EPI_STORE_T),
-             ("fc2 resid", E, F, nat.EPI_RESID_F32)]
+             ("fc2 resid", E, F, nat.EPI_RESID_F32), ("out store32", E, E, nat.EPI_STORE_F32), ("fc2 store32", E, F, nat.EPI_STORE_F32)]
     if args.cases:
         cases = [c for c in cases if any(k in c[0] for k in args.cases.split(","))]
     for name, N, K, epi in cases:
@@ -176,6 +176,23 @@ def main():
             print(f"{name:12s} {'vendor':18s} {ms*1e3:8.1f} us (min {min(times['vendor'])*1e3:8.1f}) {flops/ms/1e9:7.1f} TFLOP/s", flush=True)
         set_impl(8)
         del a, w, out
+    if not args.cases and not args.half:
+        # the fused q/k (scale + RoPE + head-major store) and v (transposed store) projections, one op = both launches
+        qkv = ops.QkvHandle(E, E // 64, dt)
+        a = rnd(M, E).to(dt)
+        wq = (rnd(3 * E, E) / math.sqrt(E)).to(dt)
+        bq = rnd(3 * E)
+        flops = 2.0 * M * 3 * E * E
+        res = {}
+        for _ in range(args.rounds):
+            for n, impl in (("gemm8", 8), ("gemm9", 9)):
+                set_impl(impl, 0)
+                res.setdefault(n, []).append(timeit(lambda: qkv(a, wq, bq, args.B, T), args.iters))
+        set_impl(8)
+        for n, ts in res.items():
+            ms = statistics.median(ts)
+            print(f"{'qkv fused':12s} {n:18s} {ms*1e3:8.1f} us (min {min(ts)*1e3:8.1f}) {flops/ms/1e9:7.1f} TFLOP/s  (q/k RoPE + v transposed, both launches, "
+                  "output allocation included)", flush=True)
     sys.exit(1 if bad else 0)
 
 
