@@ -6,7 +6,7 @@ if the shared library is missing or cannot be loaded the import of this module r
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libesmk.so")
@@ -102,6 +102,7 @@ SIGNATURES = {
     ),
     "esmk_debug_gemm_timing": (c_int, [c_void_p]),
     "esmk_debug_gemm_impl": (c_int, [c_int, c_int]),
+    "esmk_debug_set": (c_int, [c_char_p, c_double]),
     "esmk_debug_mma_selftest": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "esmk_op_split_weight": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "esmk_op_linear_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

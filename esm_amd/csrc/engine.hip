@@ -1009,6 +1009,12 @@ int esmk_debug_mma_selftest(const void* a_dev, const void* b_dev, const float* c
     return 0;
 }
 
+int esmk_debug_set(const char* key, double value) {
+    if (!key) return fail("esmk_debug_set: null key");
+    if (gemm_set_knob(key, value)) return 0;
+    return fail("esmk_debug_set: unknown key");
+}
+
 int esmk_debug_gemm_impl(int impl, int variant) {
     if (impl != 8 && impl != 9 && impl != 0) return fail("esmk_debug_gemm_impl: impl must be 8, 9 or 0 (automatic choice)");
     gemm_set_impl(impl, variant);

@@ -29,6 +29,7 @@
 // per-element predicated stores; used for shapes the fast kernel does not cover
 // (K % 64 != 0, N % 4 != 0 such as the 33-wide vocabulary projection).
 #include "gemm_epi.h"
+#include <mutex>
 #include <stdlib.h>
 #include <string.h>
 
@@ -349,28 +350,60 @@ static hipError_t dispatch(const GemmArgs& p, int epi, hipStream_t st) {
     return hipErrorInvalidValue;
 }
 
-// Which persistent kernel serves a dense call.  g_impl: 8 = gemm8 always, 9 = gemm9 wherever it applies, 0 = auto:
-// gemm9 for the calls it measurably wins in the forward (profiles/r3_gemm9_forward_ab.log, one box: the q/k and v
-// projections 22.65 -> 20.95 ms per step, the long-K residual GEMM fc2 25.7 -> 25.0; fc1 + GELU and the out projection
-// are gemm8's: their gain in the loop is lost in the single-wave epilogue), gemm8 otherwise.  Both give the same bits.
-// ESMK_GEMM_IMPL = 8 | 9 | 9:<variant> | auto;  ESMK_GEMM9_MASK = bit mask over epilogue codes for auto,
-// ESMK_GEMM9_MIN_K = shortest K of the residual GEMM that goes to gemm9 (default 2560).
+// Which persistent kernel serves a dense call.  g_impl: 8 = gemm8 always, 9 = gemm9 wherever it applies, 0 = auto.
+// Shipped policy (auto, ESMK_GEMM9_POLICY=1): EVERY dense call gemm9 supports goes to gemm9 (mask 127 = all epilogues,
+// no minimum K), full- or half-height tiles by rounds over the CUs x tile cost; gemm8 serves the generalised-addressing
+// calls.  Both give the same bits.  A/B switches: ESMK_GEMM_IMPL = 8 | 9 | 9:<variant> | auto;  ESMK_GEMM9_MASK = bit
+// mask over epilogue codes that may go to gemm9 in auto mode (default 127), ESMK_GEMM9_MIN_K = shortest K of the
+// residual GEMM that goes to gemm9 (default 0), ESMK_GEMM9_POLICY=0 = the round-3a rule.  The settings are read from
+// the environment ONCE (std::call_once: launches may come from several host threads); esmk_debug_gemm_impl overrides
+// the kernel choice only and never suppresses the other variables.
 static int g_impl = -1, g_impl_var = 0, g_mask9 = 127, g_mink9 = 0, g_auto_var = 0;
 void gemm_set_impl(int impl, int var) {
     g_impl = impl;
     g_impl_var = var;
 }
 
+// Start-up delay of one workgroup group in the residual GEMMs (gemm9.hip), as a fraction of a tile's main loop
+// (nk K tiles x ~2700 cycles); < 0 = not read yet (ESMK_RESID_DESYNC / ESMK_RESID_DESYNC_GROUP, esmk_debug_set).
+static double g_desync = -1.0;
+static int g_desync_group = -1;
+constexpr double kDesyncDefault = 0.0;
+bool gemm_set_knob(const char* key, double value) {
+    if (strcmp(key, "resid_desync") == 0) g_desync = value < 0 ? 0.0 : value;
+    else if (strcmp(key, "resid_desync_group") == 0) g_desync_group = (int)value;
+    else return false;
+    return true;
+}
+static void desync_for(GemmArgs& q, long long tiles) {
+    if (g_desync < 0) {
+        const char* e = getenv("ESMK_RESID_DESYNC");
+        g_desync = e ? atof(e) : kDesyncDefault;
+    }
+    if (g_desync_group < 0) {
+        const char* e = getenv("ESMK_RESID_DESYNC_GROUP");
+        g_desync_group = e ? atoi(e) : 0;
+    }
+    // only launches of at least two rounds of tiles: the delay is paid once, a hidden burst is won per further round
+    if (g_desync > 0 && tiles >= 512) {
+        q.desync = (int)(g_desync * (double)(q.K / 64) * 2700.0);
+        q.desync_group = g_desync_group;
+    }
+}
+
 hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipErrorInvalidValue;
-    if (g_impl < 0) {
-        const char* e = getenv("ESMK_GEMM_IMPL");
-        g_impl = (e != nullptr && e[0] == '9') ? 9 : (e != nullptr && e[0] == '8') ? 8 : 0;
-        g_impl_var = (e != nullptr && e[0] == '9' && e[1] == ':') ? atoi(e + 2) : 0;
+    static std::once_flag env_once;
+    std::call_once(env_once, [] {
+        if (g_impl < 0) {  // not set through esmk_debug_gemm_impl
+            const char* e = getenv("ESMK_GEMM_IMPL");
+            g_impl = (e != nullptr && e[0] == '9') ? 9 : (e != nullptr && e[0] == '8') ? 8 : 0;
+            g_impl_var = (e != nullptr && e[0] == '9' && e[1] == ':') ? atoi(e + 2) : 0;
+        }
         if (const char* m = getenv("ESMK_GEMM9_MASK")) g_mask9 = atoi(m);
         if (const char* k = getenv("ESMK_GEMM9_MIN_K")) g_mink9 = atoi(k);
         if (const char* v = getenv("ESMK_GEMM9_VAR")) g_auto_var = atoi(v);  // issue pattern of the auto choice (2 | 3: A/B)
-    }
+    });
     static const bool env_old = [] {
         const char* e = getenv("ESMK_GEMM");
         return e != nullptr && strcmp(e, "old") == 0;
@@ -378,7 +411,10 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
     if (!env_old && !p.force_old && !p.force_generic && !p.dbg && g_impl != 8 && gemm9_supports(p, epi)) {
         static const bool hm9 = [] { const char* e = getenv("ESMK_GEMM9_HM"); return e == nullptr || atoi(e) != 0; }();
         if (g_impl == 9 && g_impl_var >= 0) {
-            return launch_gemm9(p, epi, operand_dtype, g_impl_var, st);
+            GemmArgs q = p;
+            if (epi == EPI_RESID_F32 && g_impl_var == 0 && p.half_m <= 0)
+                desync_for(q, (long long)((p.M + 255) / 256) * ((p.N + 255) / 256));
+            return launch_gemm9(q, epi, operand_dtype, g_impl_var, st);
         }
         // auto: tile height by rounds over the CUs x cost of a tile (a half-height tile costs ~0.58 of a full one:
         // 1470 against 2400 - 2600 cycles per K tile, profiles/r3_gemm9_half_height_b4.log).  ESMK_GEMM9_POLICY=0: the
@@ -401,6 +437,7 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
             if (use9) {
                 GemmArgs q = p;
                 q.half_m = half ? 1 : 0;
+                if (epi == EPI_RESID_F32 && !half && g_auto_var == 0) desync_for(q, tiles);
                 return launch_gemm9(q, epi, operand_dtype, half ? 0 : g_auto_var, st);
             }
         }

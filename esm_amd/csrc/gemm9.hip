@@ -578,6 +578,21 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
 #pragma unroll
         for (int k = 0; k < NPC; ++k) issue1(k, st);
     }
+    // Residual epilogues are an HBM-bound burst (a 256 KiB read-modify-write per workgroup, every workgroup of the launch
+    // at the same moment: 128 MB at the HBM's own rate with the matrix pipes idle — 40 % of the out-projection's tile
+    // time, profiles/r3_gemm9_epilogues_final.log).  Tiles all cost the same, so the workgroups stay in lockstep for the
+    // whole launch; one group starting late by a fraction of a tile's main loop keeps its bursts under the other group's
+    // main loops for every following round.  Pure timing: which tile a workgroup computes, and how, is unchanged.
+    if constexpr (EPI == EPI_RESID_F32 && !HM && VAR == 0) {
+        if (p.desync > 0) {
+            const int g = p.desync_group == 0 ? (int)(blockIdx.x & 1) : p.desync_group == 1 ? (int)((blockIdx.x >> 3) & 1) : (int)(blockIdx.x & 3);
+            const long long wait = p.desync_group == 2 ? (long long)g * p.desync / 2 : (long long)g * p.desync;
+            if (wait > 0) {
+                const unsigned long long t0 = __builtin_readcyclecounter();
+                while ((long long)(__builtin_readcyclecounter() - t0) < wait) __builtin_amdgcn_s_sleep(32);
+            }
+        }
+    }
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(HALF_DMA ? 8 : (NST - 1) * NPC) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

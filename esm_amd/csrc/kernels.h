@@ -54,6 +54,10 @@ struct GemmArgs {
     int ctx_R = 0, ctx_C = 0;         // EPI_MSA_CTX geometry
     int head_dim = 64;                // EPI_QKV_ROPE / EPI_V_T: 64, or 128 (two 64-column slices per head)
     const int* row_pos = nullptr;     // EPI_QKV_ROPE: rotary position of row m (token-packed batches; default m % T)
+    // gemm9, EPI_RESID_F32: start-up delay (shader cycles) of one workgroup group — takes the HBM-bound read-modify-write
+    // epilogues of the two groups out of lockstep (set by launch_gemm; 0 = none).  desync_group: 0 = odd XCDs are late,
+    // 1 = every other workgroup of each XCD, 2 = four phases (blockIdx & 3) x desync / 2.  Results do not depend on it.
+    int desync = 0, desync_group = 0;
 };
 
 hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st);
@@ -75,6 +79,8 @@ hipError_t launch_gemm9(const GemmArgs& p, int epi, int operand_dtype, int var, 
 void gemm9_set_timing(unsigned long long* dev_buf);
 // which persistent kernel launch_gemm picks for dense calls: 8 (default) or 9; ESMK_GEMM_IMPL / esmk_debug_gemm_impl
 void gemm_set_impl(int impl, int var);
+// tuning knobs by name (esmk_debug_set): "resid_desync" (fraction of a tile's main loop), "resid_desync_group"
+bool gemm_set_knob(const char* key, double value);
 
 // ---- elementwise.hip -------------------------------------------------------------------
 // per-sequence statistics of the token matrix (esm2.py:82,86-92): scale[b] for token dropout,

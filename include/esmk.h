@@ -241,6 +241,13 @@ int esmk_debug_mma_selftest(const void* a_dev, const void* b_dev, const float* c
  * sets the same thing for a whole process. */
 int esmk_debug_gemm_impl(int impl, int variant);
 
+/* Measurement / A-B hook (no reference counterpart): named tuning knobs of the library, process wide.  Timing only —
+ * no knob changes a result bit.  "resid_desync" (>= 0): start-up delay of every other XCD's workgroups in the residual
+ * GEMMs (out-projection, fc2), as a fraction of one tile's main loop, which takes the HBM-bound read-modify-write
+ * epilogues of the two halves of the chip out of lockstep (gemm9.hip; environment: ESMK_RESID_DESYNC);
+ * "resid_desync_group": 0 = odd XCDs late, 1 = every other workgroup of each XCD, 2 = four phases. */
+int esmk_debug_set(const char* key, double value);
+
 /* Fused q/k/v projection + scaling + rotary + head split (multihead_attention.py:256-284,
  * :354-355; rotary_embedding.py:11-20).  a [B*T,E]; wqkv [3E,E]; bias [3E];
  * q_out,k_out [B,H,T,64]; vt_out [B,H,64,Tp] (V transposed, keys permuted in groups of 16,

@@ -15,7 +15,8 @@ It works on a state dict (reference key names) — it does not use esm_amd's mod
 
 ``inject`` (default None: nothing is touched, the fp32 reference computation): ``(kinds, dtype)`` rounds the named
 operand groups to a 16-bit dtype and back before they enter a contraction — "W" linear-layer weights, "A" linear-layer
-inputs, "QK" rotated q / k, "V" values, "P" softmax probabilities.  With all five it is the accuracy FLOOR of any engine
+inputs, "QK" rotated q / k, "V" values, "P" softmax probabilities ("MAPX": the returned attention maps come from the
+unrounded q / k — study hook for a split-q contact sweep; ``inject_head``: the LM head's own setting).  With all five it is the accuracy FLOOR of any engine
 that feeds 16-bit operands to fp32-accumulating matrix cores; tools/esm2_precision_study.py and the parity tests
 read the HIP engine's error against it.
 """
@@ -78,14 +79,22 @@ def attention_layer(sd, prefix, x, heads, pad_mask, need_weights, use_rope=True,
     if use_rope:  # ESM-2 (TransformerLayer(use_rotary_embeddings=True), esm2.py:57-66); ESM-1b has none
         cos, sin = rope_tables(T, d, x.device)
         q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
+    q_x, k_x = q, k
     q, k = _rnd(q, inject, "QK"), _rnd(k, inject, "QK")
     scores = q @ k.transpose(-1, -2)  # [B,H,T,T]
     if pad_mask is not None:
         scores = scores.masked_fill(pad_mask[:, None, None, :], float("-inf"))
     probs = torch.softmax(scores.float(), dim=-1)
+    maps = probs
+    if need_weights and inject is not None and "MAPX" in inject[0]:
+        # study hook: the RETURNED attention maps (contact head input) from the unrounded q / k of the same stream
+        sx = q_x @ k_x.transpose(-1, -2)
+        if pad_mask is not None:
+            sx = sx.masked_fill(pad_mask[:, None, None, :], float("-inf"))
+        maps = torch.softmax(sx.float(), dim=-1)
     ctx = (_rnd(probs, inject, "P") @ _rnd(v, inject, "V")).transpose(1, 2).reshape(B, T, E)
     out = _linear(ctx, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"], inject)
-    return out, (probs if need_weights else None)
+    return out, (maps if need_weights else None)
 
 
 def transformer_layer(sd, i, x, heads, pad_mask, need_weights, use_rope=True, inject=None):
@@ -123,6 +132,7 @@ def contact_head(sd, tokens, attentions, eos_idx=2, prepend_bos=True, append_eos
 def esm2_forward(
     sd, tokens, num_layers, heads, repr_layers=(), need_head_weights=False, return_contacts=False,
     token_dropout=True, padding_idx=1, mask_idx=32, eos_idx=2, prepend_bos=True, append_eos=True, inject=None,
+    inject_head="same",
 ):
     """reference esm/model/esm2.py:77-144.  ``sd``: fp32 state dict with the reference's keys."""
     if return_contacts:
@@ -153,9 +163,10 @@ def esm2_forward(
     if num_layers in wanted:
         reps[num_layers] = x  # esm2.py:127-128
     # RobertaLMHead, reference esm/modules.py:308-314 (weight tied to the embedding, esm2.py:71-75)
-    h = gelu(_linear(x, sd["lm_head.dense.weight"], sd["lm_head.dense.bias"], inject))
+    ih = inject if isinstance(inject_head, str) else inject_head  # the LM head may round differently from the stack
+    h = gelu(_linear(x, sd["lm_head.dense.weight"], sd["lm_head.dense.bias"], ih))
     h = layer_norm(h, sd["lm_head.layer_norm.weight"], sd["lm_head.layer_norm.bias"])
-    logits = _linear(h, sd["embed_tokens.weight"], None, inject) + sd["lm_head.bias"]
+    logits = _linear(h, sd["embed_tokens.weight"], None, ih) + sd["lm_head.bias"]
     out = {"logits": logits, "representations": reps}
     if need_head_weights:
         attentions = torch.stack(attn, 1)  # [B,L,H,T,T], esm2.py:132-139

@@ -126,3 +126,40 @@ def test_handle_kind_mix_up_is_rejected():
     rc, h = make()
     assert N.lib.esmk_msa_workspace_bytes(h, 1, 4, 16, N.OUT_LOGITS, ctypes.byref(n)) != 0 and "MSA model handle" in err()
     N.lib.esmk_destroy(h)
+
+
+def test_documented_config_struct_matches_header_and_binding():
+    """A stale document must fail CI (Weak-9): the `_Cfg` field list of INTEGRATION.md's ctypes snippet, the
+    `esmk_config` members of include/esmk.h, the shipped reference-side stub and esm_amd._native.EsmkConfig are ONE list —
+    a maintainer who copies the documented snippet must pass a struct of the size esmk_create reads."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    native = [n for n, _ in N.EsmkConfig._fields_]
+    # include/esmk.h: the int32_t members of `typedef struct { ... } esmk_config;`
+    hdr = open(os.path.join(root, "include", "esmk.h")).read()
+    body = re.search(r"typedef struct[^{]*\{(.*?)\}\s*esmk_config\s*;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    header = []
+    for decl in re.findall(r"int32_t\s+([^;]+);", body):
+        header += [v.strip() for v in decl.split(",")]
+    assert header == native, (header, native)
+    # INTEGRATION.md: the names inside the `_Cfg` class of the python snippet
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    snippet = re.search(r"class _Cfg\(ctypes\.Structure\):.*?_fields_\s*=\s*\[.*?for n in \((.*?)\)\]", doc, re.S).group(1)
+    documented = re.findall(r'"(\w+)"', snippet)
+    assert documented == native, (documented, native)
+    # ... and the constructor call of the snippet passes one value per field
+    call = re.search(r"cfg = _Cfg\((.*?)\)\s*#", doc, re.S).group(1)
+    depth, nargs = 0, 1
+    for ch in call:
+        depth += ch in "([" 
+        depth -= ch in ")]"
+        nargs += ch == "," and depth == 0
+    assert nargs == len(native), (nargs, len(native))
+    # the shipped reference-side stub
+    stub = open(os.path.join(root, "examples", "reference_binding", "_esmk.py")).read()
+    m = re.search(r"_fields_\s*=\s*\[(.*?)\]\s*\n", stub, re.S)
+    assert re.findall(r'"(\w+)"', m.group(1)) == native
+    assert ctypes.sizeof(N.EsmkConfig) == 4 * len(native) == 68

@@ -22,8 +22,10 @@ from esm_amd import _native as nat  # noqa: E402
 from esm_amd import ops  # noqa: E402
 
 
-def set_impl(impl, var=0):
+def set_impl(impl, var=0, desync=0.0, group=0):
     nat.check(nat.lib.esmk_debug_gemm_impl(impl, var))
+    nat.check(nat.lib.esmk_debug_set(b"resid_desync", float(desync)))
+    nat.check(nat.lib.esmk_debug_set(b"resid_desync_group", float(group)))
 
 
 def timeit(fn, iters):
@@ -113,6 +115,7 @@ def main():
     ap.add_argument("--half", action="store_true", help="time the half-height kernels (small batches) and their experiment variants")
     ap.add_argument("--cases", default="", help="comma-separated substrings of case names to run (default: all)")
     ap.add_argument("--dbg", action="store_true", help="also the timing-experiment variants of gemm9 (plain store only)")
+    ap.add_argument("--desync", default="", help="residual epilogues: comma-separated fraction:group arms, e.g. 0.25:0,0.5:0,0.5:1,0.5:2")
     args = ap.parse_args()
     print("device:", torch.cuda.get_device_name(0), flush=True)
     global EXACT
@@ -154,19 +157,34 @@ def main():
         if args.dbg and epi == nat.EPI_STORE_T and not args.half:
             arms += [("g9 dense", 9, 1), ("g9 spread24-61", 9, 2), ("g9 24+2k", 9, 3), ("g9 temporal-st", 9, 4096), ("g9 no-barrier", 9, 8),
                      ("g9 no-mfma", 9, 16), ("g9 no-dma", 9, 32), ("g9 no-reads", 9, 64), ("g9 no-epi", 9, 128), ("g9 mfma-only", 9, 96)]
-        times = {n: [] for n, _, _ in arms}
+        arms = [a + (0.0, 0) for a in arms]
+        if args.desync and epi == nat.EPI_RESID_F32 and not args.half:
+            for spec in args.desync.split(","):
+                frac, grp = spec.split(":")
+                arms.append((f"g9 desync {frac} g{grp}", 9, 0, float(frac), int(grp)))
+        times = {a[0]: [] for a in arms}
         if not args.no_vendor and epi == nat.EPI_STORE_T:
             times["vendor"] = []
             bias_t = bias.to(dt)
         for _ in range(args.rounds):
-            for n, impl, var in arms:
-                set_impl(impl, var)
+            for n, impl, var, dsf, dsg in arms:
+                set_impl(impl, var, dsf, dsg)
                 times[n].append(timeit(lambda: ops.linear(a, w, bias, epi, out=out, half_m=hm), args.iters))
             if "vendor" in times:
                 times["vendor"].append(timeit(lambda: torch.nn.functional.linear(a, w, bias_t), args.iters))
+        if args.desync and epi == nat.EPI_RESID_F32 and not args.half:  # a delayed start changes no bit
+            outs = []
+            for n, impl, var, dsf, dsg in arms[1:]:
+                set_impl(impl, var, dsf, dsg)
+                x0 = torch.arange(M * N, device="cuda", dtype=torch.float32).reshape(M, N).sin()
+                outs.append(ops.linear(a, w, bias, epi, out=x0))
+            same = all(torch.equal(o, outs[0]) for o in outs[1:])
+            print(f"{name:12s} desync arms bit-identical to the plain launch: {same}", flush=True)
+            bad += 0 if same else 1
+            del outs, x0
         nt = ((M + 255) // 256) * ((N + 255) // 256)
-        for n, impl, var in arms:
-            set_impl(impl, var)
+        for n, impl, var, dsf, dsg in arms:
+            set_impl(impl, var, dsf, dsg)
             loop, ep, seam, ghz = stamps(lambda: ops.linear(a, w, bias, epi, out=out, half_m=hm), min(32, nt // 256), K // 64)
             ms = statistics.median(times[n])
             print(f"{name:12s} {n:18s} {ms*1e3:8.1f} us (min {min(times[n])*1e3:8.1f}) {flops/ms/1e9:7.1f} TFLOP/s | cycles/K-tile {loop:7.1f} "
