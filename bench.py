@@ -172,7 +172,10 @@ def pmc_traffic(kernel_class, src_hash, workload="esm2_650m"):
             s = json.load(f)
         if s.get("library_src_hash") != src_hash:
             return None, f"PMC summary is from build {s.get('library_src_hash')}, this is {src_hash}"
-        return s["kernels"][kernel_class]["hbm_bytes_corrected"], s.get("git_sha")
+        # where the number comes from: the committed summary file + the hash of the library it profiled (= this library)
+        return (s["kernels"][kernel_class]["hbm_bytes_corrected"],
+                f"{os.path.relpath(PMC_SUMMARY[workload], os.path.dirname(os.path.abspath(__file__)))} (rocprofv3 PMC passes of library "
+                f"{s.get('library_src_hash')}" + (f", commit {s['git_sha']}" if s.get("git_sha") else "") + ")")
     except Exception as e:  # missing file / class
         return None, str(e)
 
@@ -531,7 +534,7 @@ def run_msa1b(args, dist, rank, world, dev):
         from oracle.msa_oracle import msa_forward
 
         ncores = cpu_threads()
-        n_rows = 8 if args.quick_baseline else 32
+        n_rows = 32  # also under --quick-baseline: an 8-row sample reads ~35 % lower than the 32-row one (Weak-2)
         small = toks[:1, :n_rows].cpu()  # bounded sample: a slice of the same MSA (depth changes the tied scale)
         c0 = time.perf_counter()
         ref = msa_forward(sd, small, L, H, repr_layers=[L])

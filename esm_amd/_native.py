@@ -35,6 +35,7 @@ class EsmkConfig(ctypes.Structure):
         ("num_positions", c_int32),
         ("ln_before", c_int32),
         ("weight_split", c_int32),
+        ("ln_fold", c_int32),
     ]
 
 
@@ -103,6 +104,13 @@ SIGNATURES = {
     "esmk_debug_gemm_timing": (c_int, [c_void_p]),
     "esmk_debug_gemm_impl": (c_int, [c_int, c_int]),
     "esmk_debug_set": (c_int, [c_char_p, c_double]),
+    "esmk_op_rowstats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "esmk_op_ln_finalize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "esmk_op_fold_weight": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "esmk_op_linear_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                  c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "esmk_op_qkv_rope_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_int, c_int, c_void_p]),
     "esmk_debug_mma_selftest": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "esmk_op_split_weight": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "esmk_op_linear_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

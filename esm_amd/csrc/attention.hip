@@ -88,11 +88,26 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
     const float* __restrict__ key_bias, const int* __restrict__ seq_info, T* __restrict__ ctx,
     float* __restrict__ lse, int H, int BH, int nq, int Tlen, int Tp, int xcdmap, int fill_mode,
-    const int* __restrict__ any_pad, AttnSegs segs) {
+    const int* __restrict__ any_pad, AttnSegs segs, int stagger) {
     __shared__ __attribute__((aligned(16))) char smem[2 * A_STAGE];
     using V8 = typename Op<T>::v8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Three workgroups share a CU, one wave of each per SIMD.  They are dispatched together and every key tile costs the
+    // same, so the three waves of a SIMD run in lockstep: all in their QK^T / PV MFMAs, then all in their exponentials —
+    // matrix pipe and VALU take turns instead of overlapping (PMC, DESIGN.md §4.2: VALU-port time + MFMA time = the
+    // kernel's duration).  `stagger` > 0 delays a workgroup by (its wave slot % 3) x stagger cycles once, at the start:
+    // the slot number (HW_ID.WAVE_ID) tells the co-resident workgroups apart.  Timing only — results do not change.
+    if (stagger > 0) {
+        __shared__ int s_slot;
+        if (tid == 0) s_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID, bits 3:0 = wave slot
+        __syncthreads();
+        const long long wait = (long long)(s_slot % 3) * stagger;
+        if (wait > 0) {
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            while ((long long)(__builtin_readcyclecounter() - t0) < wait) __builtin_amdgcn_s_sleep(8);
+        }
+    }
     const int h = lane >> 5, lm = lane & 31;
     // workgroup id -> (batch*head, query block): ids with equal id % 8 (one XCD) share bh
     int bh, qblk;
@@ -442,6 +457,12 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
                                         int operand_dtype, int fill_mode, const int* any_pad, hipStream_t st,
                                         AttnSegs segs = AttnSegs(), int n_items = 0);
 
+// start-up stagger of the co-resident workgroups in shader cycles per wave slot (attn_fwd_kernel); < 0 = read
+// ESMK_ATTN_STAGGER on the first launch; esmk_debug_set("attn_stagger", cycles)
+static int g_attn_stagger = -1;
+constexpr int kAttnStaggerDefault = 0;
+void attention_set_stagger(int cycles) { g_attn_stagger = cycles < 0 ? 0 : cycles; }
+
 hipError_t launch_attention(const void* q, const void* k, const void* vt, const float* key_bias,
                             const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
                             int operand_dtype, hipStream_t st) {
@@ -476,9 +497,14 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
         const char* e = getenv("ESMK_ATTN");
         return e ? atoi(e) : ATTN_DEFAULT_VARIANT;
     }();
+    if (g_attn_stagger < 0) {
+        const char* e = getenv("ESMK_ATTN_STAGGER");
+        g_attn_stagger = e ? atoi(e) : kAttnStaggerDefault;
+    }
+    const int stagger = g_attn_stagger;
 #define ESMK_ATTN_LAUNCH(TT, LZ, BF)                                                                      \
     hipLaunchKernelGGL((attn_fwd_kernel<TT, LZ, BF>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k,   \
-                       (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad, segs)
+                       (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad, segs, stagger)
     if (operand_dtype == ESMK_DT_BF16) {
         if (var & 2) ESMK_ATTN_LAUNCH(__bf16, 0, true);
         else ESMK_ATTN_LAUNCH(__bf16, 1, true);

@@ -486,6 +486,163 @@ ESMK_DEV size_t head_pad_index(size_t x, int d) {
     return head * 64 + (i < d / 2 ? i : 32 + (i - d / 2));
 }
 
+// ---------------------------------------------------------------------------------------------
+// LayerNorm fold (reference esm/modules.py:120-140: LayerNorm -> q/k/v projections, LayerNorm -> fc1).
+// The standalone LayerNorm pass between a residual GEMM and the GEMM that consumes the normalised rows is gone: the
+// residual epilogue (gemm9.hip, LNF producer) writes the new rows in the operand dtype together with per-row partial
+// sums, ln_finalize_kernel turns those into (mean, rstd), and the consuming GEMM runs on gamma-folded, row-centred
+// weights with rstd applied in its epilogue.  rowstats_kernel is the entry of the chain (layer 0, after the embedding).
+// ---------------------------------------------------------------------------------------------
+// x fp32 [rows, E] -> y[row][c] = T(x - mean) (row stride ldy), mean[row], rstd[row].  Same structure and traffic as
+// layernorm_kernel (one wave per two rows, non-temporal accesses); two-pass variance.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__ x, T* __restrict__ y, float* __restrict__ mean_out,
+                                                        float* __restrict__ rstd_out, int rows, int E, int ldy) {
+    constexpr int RPW = 2;
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
+    const int e4 = E >> 2;
+    f32x4 v[RPW][NCH];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = min(row0 + r, rows - 1);
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * E);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            v[r][i] = c < e4 ? __builtin_nontemporal_load(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) t += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
+        const float mean = wave_sum(t) / (float)E;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < e4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[r][i][e] -= mean;
+                    q += v[r][i][e] * v[r][i][e];
+                }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + 1e-5f);
+        const int row = row0 + r;
+        if (row >= rows) continue;
+        if (lane == 0) {
+            mean_out[row] = mean;
+            rstd_out[row] = rstd;
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < e4) {
+                typename Op<T>::v4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = Op<T>::from(v[r][i][e]);
+                __builtin_nontemporal_store(pk, reinterpret_cast<typename Op<T>::v4*>(y + (size_t)row * ldy + c * 4));
+            }
+        }
+    }
+}
+
+hipError_t launch_rowstats(const float* x, void* y, float* mean, float* rstd, int rows, int E, int ldy, int operand_dtype,
+                           hipStream_t st) {
+    if (E % 4 != 0 || rows <= 0 || ldy < E) return hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)((rows + 7) / 8);
+#define ESMK_RS(TT, N) hipLaunchKernelGGL((rowstats_kernel<TT, N>), dim3(blocks), dim3(256), 0, st, x, (TT*)y, mean, rstd, rows, E, ldy)
+#define ESMK_RS_T(TT)                  \
+    if (E <= 512) ESMK_RS(TT, 2);      \
+    else if (E <= 1280) ESMK_RS(TT, 5);  \
+    else if (E <= 2560) ESMK_RS(TT, 10); \
+    else if (E <= 5120) ESMK_RS(TT, 20); \
+    else return hipErrorInvalidValue;
+    if (operand_dtype == ESMK_DT_BF16) { ESMK_RS_T(__bf16) } else { ESMK_RS_T(_Float16) }
+#undef ESMK_RS_T
+#undef ESMK_RS
+    return hipGetLastError();
+}
+
+// part[row][parts][2] = (sum d, sum d^2) over 128-column slabs, d = x_new - mean_prev[row]  ->  mean[row] (updated in
+// place: the next producer subtracts it), rstd[row].  Summed in slab order: deterministic.
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean,
+                                                           float* __restrict__ rstd, int rows, int parts, float inv_e) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const f32x2* pr = reinterpret_cast<const f32x2*>(part) + (size_t)row * parts;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < parts; ++k) {
+        const f32x2 v = pr[k];
+        s1 += v.x;
+        s2 += v.y;
+    }
+    const float dm = s1 * inv_e;                       // mean of d: small against the spread by construction
+    const float var = fmaxf(s2 * inv_e - dm * dm, 0.f);
+    mean[row] += dm;
+    rstd[row] = 1.0f / sqrtf(var + 1e-5f);
+}
+
+hipError_t launch_ln_finalize(const float* part, float* mean, float* rstd, int rows, int parts, int E, hipStream_t st) {
+    if (rows <= 0 || parts <= 0 || E <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, part, mean, rstd, rows, parts,
+                       1.0f / (float)E);
+    return hipGetLastError();
+}
+
+// Load time: one weight row n of a linear layer that follows a LayerNorm (q/k/v projections, fc1) -> its folded image
+//   dst[map(n)][k] = T(w[n][k] gamma[k] - mean_k(w[n][.] gamma[.]))      (k < cols; pad columns of the image stay zero)
+//   bias2[map(n)]  = sum_k w[n][k] beta[k]
+// so that  LayerNorm(x) . w[n]^T + b[n]  =  rstd * ((x - c) . dst[n]^T) + b[n] + bias2[n]  for ANY per-row constant c
+// (the centred rows sum to zero up to the rounding of the image).  One workgroup per row, fp32 sums in a fixed order.
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void fold_weight_kernel(const S* __restrict__ src, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, D* __restrict__ dst,
+                                                           float* __restrict__ bias2, int cols, size_t dst_ld, int row_map, int d) {
+    __shared__ float red[2][4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const S* w = src + (size_t)n * cols;
+    float sg = 0.f, sb = 0.f;
+    for (int k = tid; k < cols; k += 256) {
+        const float v = (float)w[k];
+        sg += v * gamma[k];
+        sb += v * beta[k];
+    }
+    sg = wave_sum(sg);
+    sb = wave_sum(sb);
+    if ((tid & 63) == 0) red[0][tid >> 6] = sg, red[1][tid >> 6] = sb;
+    __syncthreads();
+    const float rowmean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)cols;
+    const float wb = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const size_t nn = row_map ? head_pad_index((size_t)n, d) : (size_t)n;
+    for (int k = tid; k < cols; k += 256) dst[nn * dst_ld + k] = (D)((float)w[k] * gamma[k] - rowmean);
+    if (tid == 0) bias2[nn] = wb;
+}
+
+hipError_t launch_fold_weight(const void* src, int src_dtype, const float* gamma, const float* beta, void* dst, int dst_dtype,
+                              float* bias2, size_t rows, size_t cols, size_t dst_ld, int row_map, int d, hipStream_t st) {
+    if (rows == 0 || cols == 0) return hipSuccess;
+#define ESMK_FW(ST, DT) \
+    hipLaunchKernelGGL((fold_weight_kernel<ST, DT>), dim3((unsigned)rows), dim3(256), 0, st, (const ST*)src, gamma, beta, (DT*)dst, bias2, \
+                       (int)cols, dst_ld, row_map, d)
+#define ESMK_FW_S(ST)                                     \
+    if (dst_dtype == ESMK_DT_F16) ESMK_FW(ST, _Float16);  \
+    else if (dst_dtype == ESMK_DT_BF16) ESMK_FW(ST, __bf16); \
+    else return hipErrorInvalidValue;
+    if (src_dtype == ESMK_DT_F32) { ESMK_FW_S(float) }
+    else if (src_dtype == ESMK_DT_F16) { ESMK_FW_S(_Float16) }
+    else if (src_dtype == ESMK_DT_BF16) { ESMK_FW_S(__bf16) }
+    else return hipErrorInvalidValue;
+#undef ESMK_FW_S
+#undef ESMK_FW
+    return hipGetLastError();
+}
+
 template <typename S, typename D>
 __global__ __launch_bounds__(256) void convert2d_kernel(const S* __restrict__ src, D* __restrict__ dst,
                                                          size_t rows, size_t cols, size_t dst_ld, int row_map,

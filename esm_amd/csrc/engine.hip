@@ -16,6 +16,8 @@ using namespace esmk;
 using namespace esmk_host;
 
 static constexpr float kLog2e = 1.4426950408889634f;
+// LayerNorm fold for handles created with esmk_config::ln_fold == 0 and no ESMK_LN_FOLD in the environment
+static constexpr bool kLnFoldDefault = false;
 
 namespace {
 thread_local std::string g_err;
@@ -71,12 +73,18 @@ void plan_packed(esmk_model* m) {
         o.ln1b = c.take(E * 4);
         o.ln2g = c.take(E * 4);
         o.ln2b = c.take(E * 4);
+        if (m->fold) {
+            o.bqkv2 = c.take(3 * EA * 4);
+            o.b12 = c.take(F * 4);
+        }
     }
     m->packed_bytes = c.off;
 }
 
 struct Workspace {
     size_t scale, key_bias, seq_info, keep, x, h, big, lse, ct_scratch, total;
+    size_t h2 = 0, ln_part = 0, ln_mean = 0, ln_rstd = 0;  // LayerNorm fold
+    int ln_parts = 0;
     size_t ct_acc, ct_row, ct_col, ct_rowp, ct_colp, ct_wt;  // contacts without attention maps (contacts.hip)
     size_t q, k, vt;  // inside big
     int Tp;
@@ -108,6 +116,16 @@ Workspace plan_workspace(const esmk_model* m, int B, int T, uint32_t flags, int 
     w.keep = c.take(m->cfg.num_positions > 0 ? N * 4 : 0);
     w.x = c.take(N * E * 4);
     w.h = c.take(N * std::max(Kp, EA) * os);
+    if (m->fold) {
+        // h: the raw rows of the residual stream in the operand dtype (A operand of q/k/v and fc1), h2: the attention
+        // context; statistics per row, padded to whole 256-row tiles (the V^T epilogue loads four rows at a time)
+        const size_t Np = (N + 255) / 256 * 256;
+        w.ln_parts = (int)((E + 127) / 128);
+        w.h2 = c.take(N * std::max(Kp, EA) * os);
+        w.ln_part = c.take(Np * w.ln_parts * 2 * 4);
+        w.ln_mean = c.take(Np * 4);
+        w.ln_rstd = c.take(Np * 4);
+    }
     const size_t qb = align_up(N * EA * os);
     const size_t vtb = align_up((size_t)B * EA * w.Tp * os);
     size_t big = 2 * qb + vtb;
@@ -229,7 +247,18 @@ int esmk_create(const esmk_config* cfg, esmk_model** out) {
         return fail("esmk_create: embed_dim must be a multiple of 8 and ffn_dim a multiple of 64");
     if (cfg->weight_split != 0 && cfg->operand_dtype != ESMK_F16)
         return fail("esmk_create: weight_split (precision mode f16x2) needs operand_dtype ESMK_F16");
+    // LayerNorm fold: explicit request, or the library default / ESMK_LN_FOLD where the configuration supports it
+    const bool fold_ok = cfg->weight_split == 0 && d <= 64;
+    if (cfg->ln_fold > 0 && !fold_ok)
+        return fail("esmk_create: ln_fold needs plain fp16 / bf16 operands (no weight_split) and head_dim <= 64");
+    bool fold = cfg->ln_fold > 0;
+    if (cfg->ln_fold == 0 && fold_ok) {
+        const char* e = getenv("ESMK_LN_FOLD");
+        fold = e ? atoi(e) != 0 : kLnFoldDefault;
+    }
     esmk_model* m = new esmk_model();
+    m->fold = fold;
+    m->fold_state.assign(cfg->num_layers, 0u);
     m->cfg = *cfg;
     m->L = cfg->num_layers;
     m->E = cfg->embed_dim;
@@ -387,6 +416,33 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
             return fail(std::string("esmk_pack_weight: bad layer index in ") + key);
         const char* sub = end + 1;
         const LayerOff& o = m->layer[l];
+        // LayerNorm fold: q/k/v and fc1 weights are packed as gamma-folded, row-centred images + W . beta (bias2); the
+        // LayerNorm parameters they fold must be in the image already, and packing one of those later marks the folded
+        // weights stale (esmk_forward refuses to run on a stale fold)
+        uint32_t& fs = m->fold_state[l];
+        auto fold_put = [&](size_t woff, size_t b2off, size_t rows, int rmap, size_t lng, size_t lnb, uint32_t need,
+                            uint32_t done) -> int {
+            if ((fs & need) != need)
+                return fail(std::string("esmk_pack_weight: ") + key + ": with the LayerNorm fold the layer's LayerNorm weight "
+                            "and bias must be packed before its q/k/v and fc1 weights");
+            if (n != rows * E)
+                return fail(std::string("esmk_pack_weight: ") + key + " has " + std::to_string(n) + " elements, expected " +
+                            std::to_string(rows * E));
+            ESMK_TRY(launch_fold_weight(src_dev, src_dtype, (const float*)(base + lng), (const float*)(base + lnb), base + woff, op,
+                                        (float*)(base + b2off), rows, E, Kp, rmap, hd, st));
+            fs |= done;
+            return 0;
+        };
+        if (m->fold) {
+            if (!strcmp(sub, "self_attn.q_proj.weight")) return fold_put(o.wqkv, o.bqkv2, E, qkmap, o.ln1g, o.ln1b, FB_LN1G | FB_LN1B, FB_WQ);
+            if (!strcmp(sub, "self_attn.k_proj.weight")) return fold_put(o.wqkv + EA * Kp * os, o.bqkv2 + EA * 4, E, qkmap, o.ln1g, o.ln1b, FB_LN1G | FB_LN1B, FB_WK);
+            if (!strcmp(sub, "self_attn.v_proj.weight")) return fold_put(o.wqkv + 2 * EA * Kp * os, o.bqkv2 + 2 * EA * 4, E, padmap, o.ln1g, o.ln1b, FB_LN1G | FB_LN1B, FB_WV);
+            if (!strcmp(sub, "fc1.weight")) return fold_put(o.w1, o.b12, F, 0, o.ln2g, o.ln2b, FB_LN2G | FB_LN2B, FB_W1);
+            if (!strcmp(sub, "self_attn_layer_norm.weight")) { fs = (fs | FB_LN1G) & ~(FB_WQ | FB_WK | FB_WV); return put(o.ln1g, ESMK_DT_F32, E); }
+            if (!strcmp(sub, "self_attn_layer_norm.bias")) { fs = (fs | FB_LN1B) & ~(FB_WQ | FB_WK | FB_WV); return put(o.ln1b, ESMK_DT_F32, E); }
+            if (!strcmp(sub, "final_layer_norm.weight")) { fs = (fs | FB_LN2G) & ~FB_W1; return put(o.ln2g, ESMK_DT_F32, E); }
+            if (!strcmp(sub, "final_layer_norm.bias")) { fs = (fs | FB_LN2B) & ~FB_W1; return put(o.ln2b, ESMK_DT_F32, E); }
+        }
         // q/k/v: output rows are head dims -> spread over 64 slots; input columns padded to Kp
         if (!strcmp(sub, "self_attn.q_proj.weight")) return putw(o.wqkv, E, E, Kp, qkmap, 0);
         if (!strcmp(sub, "self_attn.k_proj.weight")) return putw(o.wqkv + EA * Kp * os * ws, E, E, Kp, qkmap, 0);
@@ -627,8 +683,36 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         ESMK_TRY(launch_layernorm_ex(in, (const float*)(pk + go), (const float*)(pk + bo), y, y32, N, E, op, ex, st));
         return 0;
     };
+    // LayerNorm fold: hA = raw rows of the residual stream in the operand dtype (written by rowstats for
+    // layer 0, then by the residual epilogues), hB = attention context; without the fold both are `h`
+    const bool fold = m->fold;
+    if (fold)
+        for (int l = 0; l < L; ++l)
+            if ((m->fold_state[l] & FB_ALL_W) != FB_ALL_W)
+                return fail("esmk_forward: LayerNorm fold: the q/k/v or fc1 weights of layer " + std::to_string(l) +
+                            " were not packed after the layer's LayerNorm parameters");
+    void* hA = h;
+    void* hB = fold ? (void*)(ws + w.h2) : h;
+    float* ln_part = fold ? (float*)(ws + w.ln_part) : nullptr;
+    float* ln_mean = fold ? (float*)(ws + w.ln_mean) : nullptr;
+    float* ln_rstd = fold ? (float*)(ws + w.ln_rstd) : nullptr;
+    auto producer = [&](GemmArgs& a) {  // a residual GEMM that also emits the next GEMM's rows and their statistics
+        a.h16 = hA;
+        a.ldh = Kp;
+        a.ln_part = ln_part;
+        a.ln_parts = w.ln_parts;
+        a.ln_mean = ln_mean;
+    };
+    auto finalize = [&]() -> int {
+        ProfScope ps(m, st, PC_LAYERNORM, 4.0 * N * w.ln_parts, (double)N * (8.0 * w.ln_parts + 12));
+        ESMK_TRY(launch_ln_finalize(ln_part, ln_mean, ln_rstd, N, w.ln_parts, E, st));
+        return 0;
+    };
     // pad columns [E, Kp) of the activation rows must be finite (they meet zero weight columns)
-    if (Kp != E) ESMK_TRY(hipMemsetAsync(h, 0, (size_t)N * std::max(Kp, EA) * os, st));
+    if (Kp != E) {
+        ESMK_TRY(hipMemsetAsync(h, 0, (size_t)N * std::max(Kp, EA) * os, st));
+        if (fold) ESMK_TRY(hipMemsetAsync(hB, 0, (size_t)N * std::max(Kp, EA) * os, st));
+    }
 
     // esm2.py:82-95
     {
@@ -688,11 +772,20 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         if (pc)  // only the spare key tile: every row below it is a computed (finite) row
             ESMK_TRY(hipMemset2DAsync((char*)vt + (size_t)T * os, (size_t)w.Tp * os, 0, 64 * os, (size_t)EA, st));
         else if (w.Tp != T) ESMK_TRY(hipMemsetAsync(vt, 0, (size_t)B * EA * w.Tp * os, st));
-        if (lnorm(x, o.ln1g, o.ln1b, h, nullptr)) return 1;
+        if (!fold) {
+            if (lnorm(x, o.ln1g, o.ln1b, h, nullptr)) return 1;
+        } else if (l == 0) {  // entry of the fold chain: rows and statistics of the embedded stream
+            ProfScope ps(m, st, PC_LAYERNORM, 8 * NE, NE * (4 + os));
+            ESMK_TRY(launch_rowstats(x, hA, ln_mean, ln_rstd, N, E, Kp, op, st));
+        }
         g = GemmArgs();
-        g.A = h;
+        g.A = hA;
         g.W = pk + o.wqkv;
         g.bias = (const float*)(pk + o.bqkv);
+        if (fold) {
+            g.ln_rstd = ln_rstd;
+            g.bias2 = (const float*)(pk + o.bqkv2);
+        }
         g.M = N;
         g.N = 2 * EA;
         g.K = Kp;
@@ -714,6 +807,7 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         gv.row_pos = nullptr;
         gv.W = pk + o.wqkv + (size_t)2 * EA * Kp * os * wsf;     // v: weight rows [2EA,3EA)
         gv.bias = (const float*)(pk + o.bqkv) + 2 * EA;
+        if (fold) gv.bias2 = (const float*)(pk + o.bqkv2) + 2 * EA;
         gv.N = EA;
         if (fork_v) {
             // v on the side stream, after everything queued so far (the LayerNorm that wrote h, the V^T clear); the
@@ -732,12 +826,12 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
             // 4 T d flop per (query, head) pair: QK^T and PV; q,k,v read + ctx written
             ProfScope ps(m, st, PC_ATTENTION, pc ? 4.0 * pc->sum_len2 * E : 4.0 * N * (double)T * E, 4 * NE * os);
             if (pc)  // gap rows of the context (the rows of h were last read by the two GEMMs above)
-                ESMK_TRY(launch_zero_gap_rows(h, (const int*)(ws + w.tables), pc->n_seg, T, (size_t)EA * os, st));
+                ESMK_TRY(launch_zero_gap_rows(hB, (const int*)(ws + w.tables), pc->n_seg, T, (size_t)EA * os, st));
             if (pc && m->D == 128)
-                ESMK_TRY(launch_attention128_packed(q, k, vt, key_bias, h, H, T, w.Tp, segs, pc->n_items, op, st));
-            else if (pc) ESMK_TRY(launch_attention_packed(q, k, vt, key_bias, h, H, T, w.Tp, segs, pc->n_items, op, st));
-            else if (m->D == 128) ESMK_TRY(launch_attention128(q, k, vt, key_bias, seq_info, h, lse, B, H, T, w.Tp, op, st));
-            else ESMK_TRY(launch_attention(q, k, vt, key_bias, seq_info, h, lse, B, H, T, w.Tp, op, st));
+                ESMK_TRY(launch_attention128_packed(q, k, vt, key_bias, hB, H, T, w.Tp, segs, pc->n_items, op, st));
+            else if (pc) ESMK_TRY(launch_attention_packed(q, k, vt, key_bias, hB, H, T, w.Tp, segs, pc->n_items, op, st));
+            else if (m->D == 128) ESMK_TRY(launch_attention128(q, k, vt, key_bias, seq_info, hB, lse, B, H, T, w.Tp, op, st));
+            else ESMK_TRY(launch_attention(q, k, vt, key_bias, seq_info, hB, lse, B, H, T, w.Tp, op, st));
         }
         if (fused_ct && S_ct > 0) {
             // q, k and lse of this layer are still in the workspace: add the layer's channels to the
@@ -760,19 +854,28 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
                                                 attn_lowp));
         }
         g = GemmArgs();
-        g.A = h;
+        g.A = hB;
         g.W = pk + o.wo;
         g.bias = (const float*)(pk + o.bo);
         g.out = x;
         g.M = N;
         g.N = E;
         g.K = EA;
-        if (layer_gemm(PC_GEMM_OUT, g, EPI_RESID_F32, 8)) return 1;
-        if (lnorm(x, o.ln2g, o.ln2b, h, nullptr)) return 1;
+        if (fold) producer(g);
+        if (layer_gemm(PC_GEMM_OUT, g, EPI_RESID_F32, fold ? 8 + os : 8)) return 1;
+        if (fold) {
+            if (finalize()) return 1;
+        } else if (lnorm(x, o.ln2g, o.ln2b, h, nullptr)) {
+            return 1;
+        }
         g = GemmArgs();
-        g.A = h;
+        g.A = hA;
         g.W = pk + o.w1;
         g.bias = (const float*)(pk + o.b1);
+        if (fold) {
+            g.ln_rstd = ln_rstd;
+            g.bias2 = (const float*)(pk + o.b12);
+        }
         g.out = ffn;
         g.M = N;
         g.N = F;
@@ -786,7 +889,10 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         g.M = N;
         g.N = E;
         g.K = F;
-        if (layer_gemm(PC_GEMM_FC2, g, EPI_RESID_F32, 8)) return 1;
+        const bool feeds_next = fold && l + 1 < L;  // the next layer's q/k/v projections read the rows this GEMM writes
+        if (feeds_next) producer(g);
+        if (layer_gemm(PC_GEMM_FC2, g, EPI_RESID_F32, feeds_next ? 8 + os : 8)) return 1;
+        if (feeds_next && finalize()) return 1;
         if (l + 1 < L && repr_copy(l + 1, x)) return 1;  // esm2.py:117-118
     }
 
@@ -1009,9 +1115,66 @@ int esmk_debug_mma_selftest(const void* a_dev, const void* b_dev, const float* c
     return 0;
 }
 
+// ---- LayerNorm fold as single ops (tests/test_ln_fold_gpu.py) ----------------------------------------------------
+int esmk_op_rowstats(const float* x_dev, void* y_dev, float* mean_dev, float* rstd_dev, int rows, int E, int ldy,
+                     int operand_dtype, void* stream) {
+    if (!x_dev || !y_dev || !mean_dev || !rstd_dev) return fail("esmk_op_rowstats: null argument");
+    ESMK_TRY(launch_rowstats(x_dev, y_dev, mean_dev, rstd_dev, rows, E, ldy, operand_dtype, (hipStream_t)stream));
+    return 0;
+}
+
+int esmk_op_ln_finalize(const float* part_dev, float* mean_dev, float* rstd_dev, int rows, int parts, int E, void* stream) {
+    if (!part_dev || !mean_dev || !rstd_dev) return fail("esmk_op_ln_finalize: null argument");
+    ESMK_TRY(launch_ln_finalize(part_dev, mean_dev, rstd_dev, rows, parts, E, (hipStream_t)stream));
+    return 0;
+}
+
+int esmk_op_fold_weight(const void* w_dev, int w_dtype, const float* gamma_dev, const float* beta_dev, void* dst_dev,
+                        int dst_dtype, float* bias2_dev, int N, int K, int ld, void* stream) {
+    if (!w_dev || !gamma_dev || !beta_dev || !dst_dev || !bias2_dev) return fail("esmk_op_fold_weight: null argument");
+    if (N <= 0 || K <= 0 || ld < K) return fail("esmk_op_fold_weight: need N, K > 0 and ld >= K");
+    ESMK_TRY(launch_fold_weight(w_dev, w_dtype, gamma_dev, beta_dev, dst_dev, dst_dtype, bias2_dev, (size_t)N, (size_t)K,
+                                (size_t)ld, 0, 64, (hipStream_t)stream));
+    return 0;
+}
+
+int esmk_op_linear_ln(const void* a_dev, const void* w_dev, const float* bias_dev, const float* bias2_dev, void* out_dev,
+                      int M, int N, int K, int epilogue, int operand_dtype, const float* ln_rstd_dev, void* h16_dev, int ldh,
+                      float* ln_part_dev, int ln_parts, const float* ln_mean_dev, int half_m, void* stream) {
+    if (epilogue != EPI_GELU_T && epilogue != EPI_RESID_F32)
+        return fail("esmk_op_linear_ln: epilogue must be 2 (consumer: gelu) or 4 (producer: residual)");
+    GemmArgs g;
+    g.A = a_dev;
+    g.W = w_dev;
+    g.bias = bias_dev;
+    g.bias2 = bias2_dev;
+    g.out = out_dev;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.half_m = half_m;
+    if (epilogue == EPI_GELU_T) {
+        if (!ln_rstd_dev || !bias_dev) return fail("esmk_op_linear_ln: the consumer needs ln_rstd and bias");
+        g.ln_rstd = ln_rstd_dev;
+    } else {
+        if (!h16_dev || !ln_part_dev || !ln_mean_dev) return fail("esmk_op_linear_ln: the producer needs h16, ln_part and ln_mean");
+        g.h16 = h16_dev;
+        g.ldh = ldh;
+        g.ln_part = ln_part_dev;
+        g.ln_parts = ln_parts;
+        g.ln_mean = ln_mean_dev;
+    }
+    ESMK_TRY(launch_gemm(g, epilogue, operand_dtype, (hipStream_t)stream));
+    return 0;
+}
+
 int esmk_debug_set(const char* key, double value) {
     if (!key) return fail("esmk_debug_set: null key");
     if (gemm_set_knob(key, value)) return 0;
+    if (strcmp(key, "attn_stagger") == 0) {
+        attention_set_stagger((int)value);
+        return 0;
+    }
     return fail("esmk_debug_set: unknown key");
 }
 
@@ -1021,9 +1184,26 @@ int esmk_debug_gemm_impl(int impl, int variant) {
     return 0;
 }
 
+static int qkv_rope_impl(esmk_model* m, const void* a_dev, const void* wqkv_dev, const float* bias_dev,
+                         const float* bias2_dev, const float* ln_rstd_dev, void* q_out, void* k_out, void* vt_out, int B, int T,
+                         int log2_domain, void* stream);
+
 int esmk_op_qkv_rope2(esmk_model* m, const void* a_dev, const void* wqkv_dev,
                       const float* bias_dev, void* q_out, void* k_out, void* vt_out, int B, int T,
                       int log2_domain, void* stream) {
+    return qkv_rope_impl(m, a_dev, wqkv_dev, bias_dev, nullptr, nullptr, q_out, k_out, vt_out, B, T, log2_domain, stream);
+}
+
+int esmk_op_qkv_rope_ln(esmk_model* m, const void* a_dev, const void* wqkv_dev, const float* bias_dev,
+                        const float* bias2_dev, const float* ln_rstd_dev, void* q_out, void* k_out, void* vt_out, int B, int T,
+                        int log2_domain, void* stream) {
+    if (!ln_rstd_dev || !bias_dev) return fail("esmk_op_qkv_rope_ln: ln_rstd and bias are required");
+    return qkv_rope_impl(m, a_dev, wqkv_dev, bias_dev, bias2_dev, ln_rstd_dev, q_out, k_out, vt_out, B, T, log2_domain, stream);
+}
+
+static int qkv_rope_impl(esmk_model* m, const void* a_dev, const void* wqkv_dev, const float* bias_dev,
+                         const float* bias2_dev, const float* ln_rstd_dev, void* q_out, void* k_out, void* vt_out, int B, int T,
+                         int log2_domain, void* stream) {
     if (!m) return fail("esmk_op_qkv_rope: null model");
     if (m->D != 64 || m->Kp != m->E) return fail("esmk_op_qkv_rope: single-op entry point needs head_dim 64");
     hipStream_t st = (hipStream_t)stream;
@@ -1036,6 +1216,8 @@ int esmk_op_qkv_rope2(esmk_model* m, const void* a_dev, const void* wqkv_dev,
     g.A = a_dev;
     g.W = wqkv_dev;
     g.bias = bias_dev;
+    g.bias2 = bias2_dev;
+    g.ln_rstd = ln_rstd_dev;
     g.M = B * T;
     g.N = 2 * m->E;
     g.K = m->E;
@@ -1053,6 +1235,7 @@ int esmk_op_qkv_rope2(esmk_model* m, const void* a_dev, const void* wqkv_dev,
     ESMK_TRY(launch_gemm(g, EPI_QKV_ROPE, m->cfg.operand_dtype, st));
     g.W = (const char*)wqkv_dev + (size_t)2 * m->E * m->E * op_size(m->cfg.operand_dtype);
     g.bias = bias_dev + 2 * m->E;
+    if (bias2_dev) g.bias2 = bias2_dev + 2 * m->E;
     g.N = m->E;
     ESMK_TRY(launch_gemm(g, EPI_V_T, m->cfg.operand_dtype, st));
     return 0;

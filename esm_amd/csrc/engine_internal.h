@@ -29,6 +29,7 @@ struct Carve {
 // packed-parameter offsets of one TransformerLayer (reference esm/modules.py:84-142)
 struct LayerOff {
     size_t wqkv, bqkv, wo, bo, w1, b1, w2, b2, ln1g, ln1b, ln2g, ln2b;
+    size_t bqkv2 = 0, b12 = 0;  // LayerNorm fold: W . beta of the folded q/k/v and fc1 weights (GemmArgs::bias2)
 };
 // one AxialTransformerLayer (reference esm/modules.py:145-221)
 struct AttnOff {
@@ -84,6 +85,11 @@ struct esmk_model {
     // over the CUs (small batches, MSA row counts), the workgroups of one take the CUs the other leaves idle
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // LayerNorm fold: q/k/v and fc1 weights are packed gamma-folded and row-centred, the per-layer
+    // LayerNorm passes become GEMM epilogue work.  fold_state[l]: bits of FoldBits — which inputs of the fold have been
+    // packed, and which folded images are current (a LayerNorm parameter packed after its weights makes them stale).
+    bool fold = false;
+    std::vector<uint32_t> fold_state;
     // MSA Transformer (esmk_msa_create)
     bool is_msa = false;
     int npos = 0, has_msa_pos = 0;
@@ -124,6 +130,11 @@ struct ProfScope {
     ~ProfScope() {
         if (on) (void)hipEventRecord(m->prof.back().b, st);
     }
+};
+
+enum FoldBits : uint32_t {
+    FB_LN1G = 1, FB_LN1B = 2, FB_LN2G = 4, FB_LN2B = 8, FB_WQ = 16, FB_WK = 32, FB_WV = 64, FB_W1 = 128,
+    FB_ALL_W = FB_WQ | FB_WK | FB_WV | FB_W1
 };
 
 namespace esmk_host {

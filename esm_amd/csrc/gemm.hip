@@ -366,12 +366,14 @@ void gemm_set_impl(int impl, int var) {
 
 // Start-up delay of one workgroup group in the residual GEMMs (gemm9.hip), as a fraction of a tile's main loop
 // (nk K tiles x ~2700 cycles); < 0 = not read yet (ESMK_RESID_DESYNC / ESMK_RESID_DESYNC_GROUP, esmk_debug_set).
+static int g_lnf_dbg = 0;
 static double g_desync = -1.0;
 static int g_desync_group = -1;
 constexpr double kDesyncDefault = 0.0;
 bool gemm_set_knob(const char* key, double value) {
     if (strcmp(key, "resid_desync") == 0) g_desync = value < 0 ? 0.0 : value;
     else if (strcmp(key, "resid_desync_group") == 0) g_desync_group = (int)value;
+    else if (strcmp(key, "lnf_dbg") == 0) g_lnf_dbg = (int)value;
     else return false;
     return true;
 }
@@ -408,9 +410,12 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
         const char* e = getenv("ESMK_GEMM");
         return e != nullptr && strcmp(e, "old") == 0;
     }();
-    if (!env_old && !p.force_old && !p.force_generic && !p.dbg && g_impl != 8 && gemm9_supports(p, epi)) {
+    // the LayerNorm-fold forms of the epilogues exist in gemm9 only: such a call never takes another kernel
+    const bool lnf = gemm9_ln_fold(p, epi);
+    if (lnf && !gemm9_supports(p, epi)) return hipErrorInvalidValue;
+    if (lnf || (!env_old && !p.force_old && !p.force_generic && !p.dbg && g_impl != 8 && gemm9_supports(p, epi))) {
         static const bool hm9 = [] { const char* e = getenv("ESMK_GEMM9_HM"); return e == nullptr || atoi(e) != 0; }();
-        if (g_impl == 9 && g_impl_var >= 0) {
+        if (!lnf && g_impl == 9 && g_impl_var >= 0) {
             GemmArgs q = p;
             if (epi == EPI_RESID_F32 && g_impl_var == 0 && p.half_m <= 0)
                 desync_for(q, (long long)((p.M + 255) / 256) * ((p.N + 255) / 256));
@@ -422,9 +427,9 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
         static const int policy = [] { const char* e = getenv("ESMK_GEMM9_POLICY"); return e ? atoi(e) : 1; }();
         const long long tn = (p.N + 255) / 256;
         const long long tiles = (long long)((p.M + 255) / 256) * tn, tiles_h = (long long)((p.M + 127) / 128) * tn;
-        if (((g_mask9 >> epi) & 1) && (epi != EPI_RESID_F32 || p.K >= g_mink9)) {
+        if (lnf || (((g_mask9 >> epi) & 1) && (epi != EPI_RESID_F32 || p.K >= g_mink9))) {
             bool half, use9;
-            if (policy == 0) {
+            if (policy == 0 && !lnf) {
                 half = p.half_m > 0 || (p.half_m == 0 && tiles < 256 && gemm8_half_height(p));
                 use9 = half ? hm9 : tiles >= 256;
             } else {
@@ -437,8 +442,9 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
             if (use9) {
                 GemmArgs q = p;
                 q.half_m = half ? 1 : 0;
-                if (epi == EPI_RESID_F32 && !half && g_auto_var == 0) desync_for(q, tiles);
-                return launch_gemm9(q, epi, operand_dtype, half ? 0 : g_auto_var, st);
+                q.lnf_dbg = g_lnf_dbg;
+                if (epi == EPI_RESID_F32 && !half && g_auto_var == 0 && !lnf) desync_for(q, tiles);
+                return launch_gemm9(q, epi, operand_dtype, (half || lnf) ? 0 : g_auto_var, st);
             }
         }
     }

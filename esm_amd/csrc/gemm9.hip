@@ -74,9 +74,26 @@ constexpr int Q_LDS = Q_EPI + 4 * Q_SLICE;   // 160 KiB
 // NMI = 16-row blocks of the wave's block: 8 (128 rows), or 4 in the half-height kernel (64 rows).
 // SB: one 4 KiB piece buffer instead of two (the three-stage half-height kernel has 4 KiB of slice per wave; the LDS
 // executes a wave's accesses in order, so re-using the buffer is safe, only the overlap of write and read is lost).
-template <typename T, int EPI, bool FULL, int D = 4, bool NT = true, int NMI = 8, bool SB = false>
+// LNF (EPI_RESID_F32 only): the LayerNorm-fold producer (kernels.h, GemmArgs::ln_part) — the new residual rows also
+// leave as operand-dtype rows d = out_new - ln_mean[m] (the next GEMM's A operand) and as per-row partial sums
+// (sum d, sum d^2) over the wave's 128 columns; a lane visits row 32 i + 8 it + lane / 8 of the block in the four
+// pieces jb = 0..3 of row block i, adds its 16 values in that order and the eight lanes of the row combine by a fixed
+// xor butterfly: the statistics are deterministic.
+template <typename T, int EPI, bool FULL, int D = 4, bool NT = true, int NMI = 8, bool SB = false, bool LNF = false>
 ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base, int n_base, int lane, char* wl) {
+    static_assert(!LNF || EPI == EPI_RESID_F32, "the LayerNorm-fold producer is the residual epilogue");
+    constexpr bool lnp = LNF;  // (a runtime form inside the plain residual kernel was measured: the extra code changes the
+                               // register allocation of the WHOLE kernel and its main loop — same instruction stream — ran
+                               // 3110 - 3170 instead of 2630 - 2790 cycles per K tile, for every residual GEMM:
+                               // profiles/r4_ln_fold_ablation.log; so the producer stays an instantiation of its own)
     constexpr int NP = 2 * NMI;  // pieces of 32 x 32
+    constexpr int NIB = NMI / 2;  // 32-row blocks
+    float s1[4], s2[4];
+    float cmv[2][4];  // previous mean of the lane's rows 32 i + 8 it + lane / 8, fetched one 32-row block ahead
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x2 hold[4];  // operand-dtype columns of the pair's first piece
+    T* h16 = reinterpret_cast<T*>(p.h16);
     if constexpr (!FULL)
         if (n_base >= p.N || m_base >= p.M) return;  // wave uniform
     float* out = reinterpret_cast<float*>(p.out);
@@ -97,10 +114,26 @@ ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base,
 #pragma unroll
         for (int d = 0; d < D; ++d) load_old(old[d], d);
     }
+    auto load_means = [&](int i) ESMK_INL {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int m = m_base + 32 * i + it * 8 + (lane >> 3);
+            cmv[i & 1][it] = (p.lnf_dbg & 4) ? 0.f : p.ln_mean[FULL ? m : min(m, p.M - 1)];
+        }
+    };
+    if constexpr (LNF)
+        if (lnp) load_means(0);
 #pragma unroll
     for (int piece = 0; piece < NP; ++piece) {
         const int i = piece >> 2, jb = piece & 3;
         char* sl = wl + (SB ? 0 : (piece & 1) * 4096);
+        if constexpr (LNF) {
+            if (jb == 0 && lnp) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) s1[it] = s2[it] = 0.f;
+                if (i + 1 < NIB) load_means(i + 1);
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int mi2 = q >> 1, nj2 = q & 1;
@@ -126,15 +159,71 @@ ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base,
                 v = f32x4{o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3] + v[3]};
             }
             const int m = m_base + 32 * i + r, n = n_base + 32 * jb + cc * 4;
-            if (FULL || (m < p.M && n < p.N)) {
+            const bool inside = FULL || (m < p.M && n < p.N);
+            if (inside) {
                 // non-temporal: a tile's output is not read again by this launch; kept out of the way of the operand
                 // panels in the XCD's L2 (profiles/r3_gemm9_mi16_variants.log: +4 .. 7 % on the K = 1280 shapes)
                 if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (size_t)m * ldc + n));
                 else *reinterpret_cast<f32x4*>(out + (size_t)m * ldc + n) = v;
             }
+            if (LNF && lnp) {
+                const float c = cmv[i & 1][it];
+                float d0 = v[0] - c, d1 = v[1] - c, d2 = v[2] - c, d3 = v[3] - c;
+                if (!inside) d0 = d1 = d2 = d3 = 0.f;
+                // spelled-out operation order (no compiler contraction choices): every instantiation of this
+                // epilogue — full / clipped blocks, both tile heights — produces the same statistics bits
+                s1[it] += (d0 + d1) + (d2 + d3);
+                s2[it] = __builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, __builtin_fmaf(d0, d0, s2[it]))));
+                typename Op<T>::v4 pk;
+                pk[0] = Op<T>::from(d0), pk[1] = Op<T>::from(d1), pk[2] = Op<T>::from(d2), pk[3] = Op<T>::from(d3);
+                // The operand-dtype rows leave as whole 128-byte lines, 16 bytes per lane: a lane holds 4 columns (8 bytes)
+                // of piece jb; pieces are taken in pairs (columns 64 (jb / 2) .. + 63 of the row) and neighbouring lanes
+                // swap halves — the even lane of a pair stores 8 columns of the first piece, the odd lane 8 columns of the
+                // second.  (As 8-byte stores per piece — half lines, two instructions per line — the epilogue took twice
+                // its time: profiles/r4_ln_fold_first.log, r4_ln_fold_second.log.)
+                const u32x2 cur = __builtin_bit_cast(u32x2, pk);
+                if ((jb & 1) == 0) {
+                    hold[it] = cur;
+                } else {
+                    const bool odd = (lane & 1) != 0;
+                    const u32x2 prev = hold[it];
+                    const u32x2 send = odd ? prev : cur;
+                    u32x2 recv;  // quad_perm [1, 0, 3, 2]: the neighbouring lane's words
+                    recv.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.x, 0xB1, 0xf, 0xf, true);
+                    recv.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xf, 0xf, true);
+                    const u32x4 o = odd ? u32x4{recv.x, recv.y, cur.x, cur.y} : u32x4{prev.x, prev.y, recv.x, recv.y};
+                    const int col = n_base + (odd ? 32 * jb + 4 * (cc - 1) : 32 * (jb - 1) + 4 * cc);
+                    if ((FULL || (m < p.M && col < p.N)) && !(p.lnf_dbg & 1)) {
+                        auto* hd = reinterpret_cast<u32x4*>(h16 + (size_t)m * p.ldh + col);
+                        if constexpr (NT) __builtin_nontemporal_store(o, hd);
+                        else *hd = o;
+                    }
+                }
+            }
         }
         if constexpr (EPI == EPI_RESID_F32)
             if (piece + D < NP) load_old(old[piece % D], piece + D);
+        if constexpr (LNF) {
+            if (jb == 3 && lnp && !(p.lnf_dbg & 2)) {  // the wave's 128 columns of rows 32 i .. 32 i + 31 are complete
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    // the row's eight lanes: lane l adds lanes l-1, then l-2, l-3, then l-4 .. l-7 (DPP row_shr, zeros
+                    // shifted in at the start of a 16-lane row) -> lanes 7 and 15 of the row hold the two 8-lane sums
+                    float a = s1[it], b = s2[it];
+                    a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x111, 0xf, 0xf, true));
+                    b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x111, 0xf, 0xf, true));
+                    a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x112, 0xf, 0xf, true));
+                    b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x112, 0xf, 0xf, true));
+                    a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x114, 0xf, 0xf, true));
+                    b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x114, 0xf, 0xf, true));
+                    const int m = m_base + 32 * i + it * 8 + (lane >> 3);
+                    if ((lane & 7) == 7 && (FULL || m < p.M)) {
+                        f32x2 st = {a, b};
+                        *reinterpret_cast<f32x2*>(p.ln_part + ((size_t)m * p.ln_parts + (n_base >> 7)) * 2) = st;
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -146,9 +235,31 @@ ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base,
 // right behind round r's reads and land while round r's values go through GELU / RoPE / the conversion — a single
 // wave has no partner to hide the LDS round trip behind (15.7k -> cycles of the first version were half latency).
 // RR = rows per round: 32 (8 KiB image), or 16 (4 KiB: the three-stage half-height kernel).
-template <typename T, int EPI, bool FULL, bool NT = false, int NMI = 8, int RR = 32>
+// LNF: LayerNorm-fold consumer (kernels.h, GemmArgs::ln_rstd): the accumulators hold raw_row . W''^T (no bias); the value
+// is ln_rstd[m] * acc + (bias[n] + bias2[n]) — ONE fma per element; in the q / k epilogue it replaces the multiply by the
+// q scale (rstd * scale and (bias + bias2) * scale are formed once per row / per 64-column half).
+template <typename T, int EPI, bool FULL, bool NT = false, int NMI = 8, int RR = 32, bool LNF = false>
 ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base, int n_base, int lane, char* wl) {
     using V8 = typename Op<T>::v8;
+    float bs1[8], bs2[8];  // LNF: bias + bias2 of the lane's columns in the current 64-column half (q: times the scale)
+    // LNF: rstd of every row this lane visits (row RR i + RPI it + lane / LPR of the block), all loads in flight at once —
+    // one dependent load per row visit cost ~7 k cycles per tile (profiles/r4_ln_fold_first.log)
+    constexpr int LPR = EPI == EPI_QKV_ROPE ? 4 : 8;  // lanes per row of a round
+    constexpr int RPI = 64 / LPR;                      // rows per 64-lane pass
+    constexpr int NIT = RR / RPI;
+    constexpr int NI_ = NMI * 16 / RR;
+    float rsv[LNF ? NI_ : 1][NIT];
+    if constexpr (LNF) {
+        if (FULL || m_base < p.M) {
+#pragma unroll
+            for (int i = 0; i < NI_; ++i)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int m = m_base + RR * i + RPI * it + lane / LPR;
+                    rsv[i][it] = p.ln_rstd[FULL ? m : min(m, p.M - 1)];
+                }
+        }
+    }
     constexpr int NI = NMI * 16 / RR;  // row blocks of RR rows
     constexpr int NR = 2 * NI;         // rounds: [64-column half][row block]
     constexpr int MB = RR / 16;        // 16-row MFMA blocks per round
@@ -202,13 +313,33 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base, i
             const int head = (nb - which * p.E) >> 6;
             T* qk = reinterpret_cast<T*>(which == 0 ? p.q : p.k);
             const float sc = which == 0 ? p.scaling : 1.0f;
+            if constexpr (LNF) {
+                if (i == 0) {  // first round of this 64-column half
+                    const int c0 = nb + 8 * (lane & 3);
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        f32x4 a = *reinterpret_cast<const f32x4*>(p.bias + c0 + 4 * e2), b = *reinterpret_cast<const f32x4*>(p.bias + c0 + 32 + 4 * e2);
+                        if (p.bias2 != nullptr) {
+                            const f32x4 a2 = *reinterpret_cast<const f32x4*>(p.bias2 + c0 + 4 * e2), b2 = *reinterpret_cast<const f32x4*>(p.bias2 + c0 + 32 + 4 * e2);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) a[e] += a2[e], b[e] += b2[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bs1[4 * e2 + e] = a[e] * sc, bs2[4 * e2 + e] = b[e] * sc;
+                    }
+                }
+            }
 #pragma unroll
             for (int it = 0; it < RR / 16; ++it) {
                 const int slot = it * 64 + lane;
                 const int r = slot >> 2, g4 = slot & 3;  // row of the round, dims [8 g4, 8 g4 + 8)
                 const int mm = m_base + RR * i + r;
                 const int m = FULL ? mm : min(mm, p.M - 1);
-                const int b = m / p.T, tt = m - b * p.T;
+                const int b = m / p.T;
+                // rotary position: the row's place in its sequence, or (token-packed batches) in its segment
+                const int tt = p.row_pos != nullptr ? p.row_pos[m] : m - b * p.T;
+                float rs = sc;
+                if constexpr (LNF) rs = rsv[i][it] * sc;
                 float y1[8], y2[8];
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
@@ -218,8 +349,8 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base, i
                     for (int e = 0; e < 4; ++e) {
                         // the contraction hipcc chose for epilogue8's `a1*c - a2*s`, `a2*c + a1*s`, spelled out:
                         // bit-identical q / k whichever kernel ran (packed == padded == alone stays exact)
-                        const float x1 = raw[4 * it + e2][e] * sc;
-                        const float x2 = raw[4 * it + 2 + e2][e] * sc;
+                        const float x1 = LNF ? __builtin_fmaf(raw[4 * it + e2][e], rs, bs1[4 * e2 + e]) : raw[4 * it + e2][e] * sc;
+                        const float x2 = LNF ? __builtin_fmaf(raw[4 * it + 2 + e2][e], rs, bs2[4 * e2 + e]) : raw[4 * it + 2 + e2][e] * sc;
                         y1[4 * e2 + e] = __builtin_fmaf(x1, c[e], -(x2 * s[e]));
                         y2[4 * e2 + e] = __builtin_fmaf(x2, c[e], x1 * s[e]);
                     }
@@ -228,7 +359,7 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base, i
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o1[e] = Op<T>::from(y1[e]), o2[e] = Op<T>::from(y2[e]);
                 if (FULL || mm < p.M) {
-                    T* dst = qk + ((size_t)(b * p.H + head) * p.T + tt) * 64 + 8 * g4;
+                    T* dst = qk + ((size_t)(b * p.H + head) * p.T + (m - b * p.T)) * 64 + 8 * g4;
                     if constexpr (NT) {
                         __builtin_nontemporal_store(o1, reinterpret_cast<V8*>(dst));
                         __builtin_nontemporal_store(o2, reinterpret_cast<V8*>(dst + 32));
@@ -240,6 +371,22 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base, i
             }
         } else {
             T* out = reinterpret_cast<T*>(p.out);
+            if constexpr (LNF) {
+                if (i == 0) {  // first round of this 64-column half
+                    const int c0 = FULL ? nb + 8 * (lane & 7) : min(nb + 8 * (lane & 7), p.N - 8);
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        f32x4 a = *reinterpret_cast<const f32x4*>(p.bias + c0 + 4 * e2);
+                        if (p.bias2 != nullptr) {
+                            const f32x4 a2 = *reinterpret_cast<const f32x4*>(p.bias2 + c0 + 4 * e2);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) a[e] += a2[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bs1[4 * e2 + e] = a[e];
+                    }
+                }
+            }
 #pragma unroll
             for (int it = 0; it < RR / 8; ++it) {
                 const int slot = it * 64 + lane;
@@ -249,6 +396,11 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base, i
                 for (int e2 = 0; e2 < 2; ++e2)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[4 * e2 + e] = raw[2 * it + e2][e];
+                if constexpr (LNF) {
+                    const float rs = rsv[i][it];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], rs, bs1[e]);
+                }
                 if constexpr (EPI == EPI_GELU_T) gelu_fast_x8(v);  // four chains: one wave per SIMD has no partner to fill VALU gaps
                 V8 o;
 #pragma unroll
@@ -279,8 +431,12 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base, i
 // HM: half-height tiles (128 x 256; wave blocks 64 x 128) for launches that leave CUs idle with 256-row tiles (small
 // batches).  Same LDS image (the activation half of a buffer is half used), 4 + 8 pieces per wave and K tile, 32 MFMA
 // slots; every output element sees the same MFMA sequence over K as in the full-height kernel: same bits.
-template <typename T, int EPI, int VAR = 0, bool HM = false>
+// LNF: LayerNorm fold (kernels.h): EPI_RESID_F32 = producer (second operand-dtype output + row statistics),
+// EPI_QKV_ROPE / EPI_V_T / EPI_GELU_T = consumer (accumulators start from 0, row scale + bias in the epilogue).
+template <typename T, int EPI, int VAR = 0, bool HM = false, bool LNF = false>
 __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long long* timing) {
+    static_assert(!LNF || EPI == EPI_RESID_F32 || EPI == EPI_QKV_ROPE || EPI == EPI_V_T || EPI == EPI_GELU_T, "LayerNorm fold: epilogue");
+    constexpr bool LNC = LNF && EPI != EPI_RESID_F32;  // consumer
     constexpr int TM = HM ? 128 : 256;     // tile height
     constexpr int NMI = HM ? 4 : 8;        // 16-row blocks of a wave's block
     constexpr int NPC = NMI + 8;           // DMA pieces per wave and K tile
@@ -472,7 +628,7 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     // tile's epilogue, so they land under it — the scalar-load form cost ~2k cycles of serialized waits per tile seam.
     auto load_bias = [&](int n_base) ESMK_INL {
         bool done = false;
-        if constexpr (EPI != EPI_V_T) {
+        if constexpr (EPI != EPI_V_T && !LNC) {
             if (p.bias != nullptr) {
                 const int g4 = lane >> 4;
                 if (n_base + 128 <= p.N) {
@@ -642,20 +798,22 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
 #pragma unroll
                 for (int mi = 0; mi < NMI; ++mi) asm volatile("" ::"a"(acc[nj][mi]));
         } else if constexpr (EPI == EPI_STORE_F32 || EPI == EPI_GELU_F32 || EPI == EPI_RESID_F32) {
-            if (full) epilogue9_f32<T, EPI, true, 4, NTS, NMI, HM>(p, acc, m_base, n_base, lane, slice);
-            else epilogue9_f32<T, EPI, false, 4, NTS, NMI, HM>(p, acc, m_base, n_base, lane, slice);
+            // residual pieces in flight: 4, or 3 next to the LayerNorm-fold producer's extra state
+            constexpr int RD = LNF ? 3 : 4;
+            if (full) epilogue9_f32<T, EPI, true, RD, NTS, NMI, HM, LNF>(p, acc, m_base, n_base, lane, slice);
+            else epilogue9_f32<T, EPI, false, RD, NTS, NMI, HM, LNF>(p, acc, m_base, n_base, lane, slice);
         } else if constexpr (EPI == EPI_V_T) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int nb = n_base + 64 * hf;
                 const bool f2 = (m_base + WRM <= p.M) && (nb + 64 <= p.N) && (p.T % 32 == 0);
                 char* sl2 = slice + (HM ? 0 : hf * 4096);
-                if (f2) epilogue8m<T, EPI, true, false, false, NMI / 2, 8, NTS, NMI>(p, acc, 4 * hf, m_base, nb, lane, sl2, 0, 0, 0);
-                else epilogue8m<T, EPI, false, false, false, NMI / 2, 8, NTS, NMI>(p, acc, 4 * hf, m_base, nb, lane, sl2, 0, 0, 0);
+                if (f2) epilogue8m<T, EPI, true, false, false, NMI / 2, 8, NTS, NMI, LNF>(p, acc, 4 * hf, m_base, nb, lane, sl2, 0, 0, 0);
+                else epilogue8m<T, EPI, false, false, false, NMI / 2, 8, NTS, NMI, LNF>(p, acc, 4 * hf, m_base, nb, lane, sl2, 0, 0, 0);
             }
         } else {
-            if (full) epilogue9_t<T, EPI, true, NTS, NMI, HM ? 16 : 32>(p, acc, m_base, n_base, lane, slice);
-            else epilogue9_t<T, EPI, false, NTS, NMI, HM ? 16 : 32>(p, acc, m_base, n_base, lane, slice);
+            if (full) epilogue9_t<T, EPI, true, NTS, NMI, HM ? 16 : 32, LNF>(p, acc, m_base, n_base, lane, slice);
+            else epilogue9_t<T, EPI, false, NTS, NMI, HM ? 16 : 32, LNF>(p, acc, m_base, n_base, lane, slice);
         }
         if constexpr (!BIAS_EARLY) next_bias();
         stamp(it, 2);
@@ -681,10 +839,10 @@ static int num_workgroups9() {
     return n;
 }
 
-template <typename T, int EPI, int VAR = 0, bool HM = false>
+template <typename T, int EPI, int VAR = 0, bool HM = false, bool LNF = false>
 static hipError_t launch9(GemmArgs p, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = gemm9_kernel<T, EPI, VAR, HM>;
+    auto kern = gemm9_kernel<T, EPI, VAR, HM, LNF>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
@@ -703,12 +861,20 @@ static hipError_t launch9(GemmArgs p, hipStream_t st) {
     return hipGetLastError();
 }
 
+// LayerNorm fold requested for this call? (producer: EPI_RESID_F32 + ln_part; consumer: q/k, v, fc1 epilogues + ln_rstd)
+bool gemm9_ln_fold(const GemmArgs& p, int epi) {
+    if (epi == EPI_RESID_F32) return p.ln_part != nullptr;
+    if (epi == EPI_QKV_ROPE || epi == EPI_V_T || epi == EPI_GELU_T) return p.ln_rstd != nullptr;
+    return false;
+}
+
 bool gemm9_supports(const GemmArgs& p, int epi) {
     if (p.K % 64 != 0 || p.N % 8 != 0 || p.M <= 0) return false;
     // of the generalised addressing only the split-weight form (own activation row stride, repeated activation K tiles)
     if (p.w_row_bytes || p.a_kt_bytes || p.w_kt_bytes || p.batch > 1 || p.n_valid > 0 || p.ldc > 0 || p.row_keep != nullptr ||
-        p.vt_rows > 0 || p.rowmap_R > 0 || epi == EPI_MSA_CTX || p.head_dim != 64 || p.row_pos != nullptr)
+        p.vt_rows > 0 || p.rowmap_R > 0 || epi == EPI_MSA_CTX || p.head_dim != 64)
         return false;
+    if (gemm9_ln_fold(p, epi) && p.a_kt_repeat) return false;  // the fold has no split-weight form
     if (p.a_row_bytes && (p.a_row_bytes % 16 != 0)) return false;
     if ((epi == EPI_QKV_ROPE || epi == EPI_V_T) && p.N % 64 != 0) return false;
     if ((long long)256 * p.K * 2 > 0x7fffffffLL) return false;  // a panel must fit a buffer descriptor
@@ -742,6 +908,27 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
                 case 224: return launch9<T, EPI_STORE_T, 224, true>(p, st);
             }
         }
+    }
+    if (gemm9_ln_fold(p, epi)) {  // LayerNorm fold: producer / consumer forms of the four epilogues, both tile heights
+        if (var != 0) return hipErrorInvalidValue;
+        if (epi == EPI_RESID_F32 && (p.h16 == nullptr || p.ln_mean == nullptr || p.ldh < p.N || p.ln_parts < (p.N + 127) / 128))
+            return hipErrorInvalidValue;
+        if (epi != EPI_RESID_F32 && p.bias == nullptr) return hipErrorInvalidValue;
+        if (p.half_m > 0) {
+            switch (epi) {
+                case EPI_RESID_F32: return launch9<T, EPI_RESID_F32, 0, true, true>(p, st);
+                case EPI_QKV_ROPE: return launch9<T, EPI_QKV_ROPE, 0, true, true>(p, st);
+                case EPI_V_T: return launch9<T, EPI_V_T, 0, true, true>(p, st);
+                case EPI_GELU_T: return launch9<T, EPI_GELU_T, 0, true, true>(p, st);
+            }
+        }
+        switch (epi) {
+            case EPI_RESID_F32: return launch9<T, EPI_RESID_F32, 0, false, true>(p, st);
+            case EPI_QKV_ROPE: return launch9<T, EPI_QKV_ROPE, 0, false, true>(p, st);
+            case EPI_V_T: return launch9<T, EPI_V_T, 0, false, true>(p, st);
+            case EPI_GELU_T: return launch9<T, EPI_GELU_T, 0, false, true>(p, st);
+        }
+        return hipErrorInvalidValue;
     }
     if (var == 0 && p.half_m > 0) {  // half-height tiles
         switch (epi) {

@@ -70,7 +70,9 @@ ESMK_DEV typename Op<T>::v4 pack4_(float a, float b, float c, float d) {
 // NI = number of 32-row pieces of the wave's block: 4 (128 rows), or 2 in the half-height tile mode (HM).
 // NT: the aligned global stores carry the non-temporal policy (large launches: the output is not read again by this
 // launch and should not push the operand panels out of the XCD's L2).
-template <typename T, int EPI, bool FULL, bool NOSTORE = false, bool GEN = false, int NI = 4, int NJT = 4, bool NT = false, int NMI = 8>
+// LNF (gemm9, EPI_V_T only): LayerNorm-fold consumer — value = ln_rstd[token] * acc + (bias + bias2)[channel]
+// (kernels.h, GemmArgs::ln_rstd; the buffer is padded to whole 256-row tiles, so the 4-token loads never leave it).
+template <typename T, int EPI, bool FULL, bool NOSTORE = false, bool GEN = false, int NI = 4, int NJT = 4, bool NT = false, int NMI = 8, bool LNF = false>
 ESMK_DEV void epilogue8m(const GemmArgs& p, f32x4 (&acc)[NJT][NMI], int nj0, int m_base, int n_base, int lane,
                          char* wl, size_t out_off, int zo, int zi) {
     using V4 = typename Op<T>::v4;
@@ -87,7 +89,11 @@ ESMK_DEV void epilogue8m(const GemmArgs& p, f32x4 (&acc)[NJT][NMI], int nj0, int
         T* vt = reinterpret_cast<T*>(p.vt);
         float bvn[4];
 #pragma unroll
-        for (int nj = 0; nj < 4; ++nj) bvn[nj] = p.bias[n_base + 16 * nj + l16];
+        for (int nj = 0; nj < 4; ++nj) {
+            bvn[nj] = p.bias[n_base + 16 * nj + l16];
+            if constexpr (LNF)
+                if (p.bias2 != nullptr) bvn[nj] += p.bias2[n_base + 16 * nj + l16];
+        }
         const bool aligned = FULL || (p.T % 32 == 0);  // a 32-token piece = one aligned run of one sequence
         const bool perm = !GEN || (p.vt_rows == 0);  // ESM-2 attention consumes permuted keys, the MSA context GEMM plain ones
         // row index of vt for sequence `sq`: ESM-2 [B,H,64,Tp]; MSA row attention [B,H,R,64,Tp], sq = (b,r)
@@ -98,6 +104,12 @@ ESMK_DEV void epilogue8m(const GemmArgs& p, f32x4 (&acc)[NJT][NMI], int nj0, int
         };
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
+            f32x4 rs4[2];
+            if constexpr (LNF) {
+#pragma unroll
+                for (int mi2 = 0; mi2 < 2; ++mi2)
+                    rs4[mi2] = *reinterpret_cast<const f32x4*>(p.ln_rstd + m_base + 32 * i + 16 * mi2 + 4 * g4);
+            }
             // LDS piece: 64 rows (dv) x 64 B (32 tokens); 16-byte chunk c holds 8 token slots
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) {
@@ -110,6 +122,12 @@ ESMK_DEV void epilogue8m(const GemmArgs& p, f32x4 (&acc)[NJT][NMI], int nj0, int
                     const int chunk = 2 * mi2 + ((aligned && perm) ? (g4 & 1) : (g4 >> 1));
                     const int half = (aligned && perm) ? (g4 >> 1) : (g4 & 1);
                     const f32x4& a = acc[nj0 + nj][2 * i + mi2];
+                    if constexpr (LNF) {
+                        const f32x4& rs = rs4[mi2];
+                        *reinterpret_cast<V4*>(wl + dv * 64 + ((chunk ^ ((dv >> 1) & 3)) << 4) + 8 * half) =
+                            pack4_<T>(__builtin_fmaf(a[0], rs[0], bv), __builtin_fmaf(a[1], rs[1], bv), __builtin_fmaf(a[2], rs[2], bv),
+                                      __builtin_fmaf(a[3], rs[3], bv));
+                    } else
                     *reinterpret_cast<V4*>(wl + dv * 64 + ((chunk ^ ((dv >> 1) & 3)) << 4) + 8 * half) =
                         pack4_<T>(a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv);
                 }

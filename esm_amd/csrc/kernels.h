@@ -54,6 +54,23 @@ struct GemmArgs {
     int ctx_R = 0, ctx_C = 0;         // EPI_MSA_CTX geometry
     int head_dim = 64;                // EPI_QKV_ROPE / EPI_V_T: 64, or 128 (two 64-column slices per head)
     const int* row_pos = nullptr;     // EPI_QKV_ROPE: rotary position of row m (token-packed batches; default m % T)
+    // ---- LayerNorm fold (gemm9 only) ------------------------------------------------------------
+    // Producer = EPI_RESID_F32 with ln_part != null: besides out[m][n] += acc + bias it writes the operand-dtype copy
+    // h16[m][n] = T(out_new - ln_mean[m]) (row stride ldh) that the next GEMM takes as its A operand, and the partial
+    // row sums ln_part[(m * ln_parts + n_base / 128) * 2 + {0, 1}] = (sum d, sum d^2) over the wave's 128 columns,
+    // d = out_new - ln_mean[m] (ln_mean: the row's PREVIOUS mean — any per-row constant cancels against the centred
+    // weights; it only keeps the rounding of h16 relative to the row's spread instead of its offset).
+    // Consumer = EPI_QKV_ROPE / EPI_V_T / EPI_GELU_T with ln_rstd != null: W holds gamma-folded, row-centred weights,
+    // the accumulators start from 0 and the epilogue computes  ln_rstd[m] * acc + (bias[n] + bias2[n])
+    // (bias2 = W . beta, written when the weights were folded).
+    void* h16 = nullptr;
+    int ldh = 0;
+    float* ln_part = nullptr;
+    int ln_parts = 0;
+    const float* ln_mean = nullptr;
+    const float* ln_rstd = nullptr;
+    const float* bias2 = nullptr;
+    int lnf_dbg = 0;  // timing experiments on the producer (results incomplete): 1 no h16 stores, 2 no statistics, 4 no mean loads
     // gemm9, EPI_RESID_F32: start-up delay (shader cycles) of one workgroup group — takes the HBM-bound read-modify-write
     // epilogues of the two groups out of lockstep (set by launch_gemm; 0 = none).  desync_group: 0 = odd XCDs are late,
     // 1 = every other workgroup of each XCD, 2 = four phases (blockIdx & 3) x desync / 2.  Results do not depend on it.
@@ -75,12 +92,14 @@ void gemm8_set_timing(unsigned long long* dev_buf);
 // gemm9.hip: the same contract on one wave per SIMD (128 x 128 wave blocks); dense operands only.  var selects the
 // DMA schedule (0: 8 + 8 pieces, 1: 6 + 5 + 5) or a timing experiment (gemm9.hip)
 bool gemm9_supports(const GemmArgs& p, int epi);
+bool gemm9_ln_fold(const GemmArgs& p, int epi);  // the call asks for the LayerNorm-fold form of its epilogue
 hipError_t launch_gemm9(const GemmArgs& p, int epi, int operand_dtype, int var, hipStream_t st);
 void gemm9_set_timing(unsigned long long* dev_buf);
 // which persistent kernel launch_gemm picks for dense calls: 8 (default) or 9; ESMK_GEMM_IMPL / esmk_debug_gemm_impl
 void gemm_set_impl(int impl, int var);
 // tuning knobs by name (esmk_debug_set): "resid_desync" (fraction of a tile's main loop), "resid_desync_group"
 bool gemm_set_knob(const char* key, double value);
+void attention_set_stagger(int cycles);  // attention.hip: start-up stagger of co-resident workgroups (timing only)
 
 // ---- elementwise.hip -------------------------------------------------------------------
 // per-sequence statistics of the token matrix (esm2.py:82,86-92): scale[b] for token dropout,
@@ -101,6 +120,13 @@ hipError_t launch_embed(const int64_t* tokens, const float* table, const float* 
 // LayerNorm(E, eps=1e-5) (modules.py:68-81): fp32 rows -> operand-dtype and/or fp32 rows
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* y,
                             float* y32, int rows, int E, int operand_dtype, hipStream_t st);
+// LayerNorm fold (elementwise.hip): entry of the chain, statistics from the producers' partial sums,
+// load-time weight fold
+hipError_t launch_rowstats(const float* x, void* y, float* mean, float* rstd, int rows, int E, int ldy, int operand_dtype,
+                           hipStream_t st);
+hipError_t launch_ln_finalize(const float* part, float* mean, float* rstd, int rows, int parts, int E, hipStream_t st);
+hipError_t launch_fold_weight(const void* src, int src_dtype, const float* gamma, const float* beta, void* dst, int dst_dtype,
+                              float* bias2, size_t rows, size_t cols, size_t dst_ld, int row_map, int d, hipStream_t st);
 // MSA Transformer variants of the same kernel: output rows scaled by row_keep[row] (padded positions
 // zeroed, msa_transformer.py:171-172) and/or written in (b,c,r) row order for the column-attention block
 struct LnExtra {

@@ -98,6 +98,13 @@ def _weight_split():
     return os.environ.get("ESM_AMD_OPERAND", "").lower() in ("f16x2", "fp16x2")
 
 
+def _ln_fold():
+    """``ESM_AMD_LN_FOLD=1|0``: LayerNorm fold of the engine (esmk_config.ln_fold) on / off; unset = the
+    library's default.  ESM-2 / ESM-1b engines with plain fp16 / bf16 operands and head_dim <= 64."""
+    v = os.environ.get("ESM_AMD_LN_FOLD", "")
+    return 0 if v == "" else (1 if v not in ("0", "off", "false") else -1)
+
+
 def _operand_dtype_for(param_dtype):
     env = os.environ.get("ESM_AMD_OPERAND", "").lower()
     if env in ("bf16", "bfloat16"):
@@ -163,6 +170,7 @@ class _Engine:
         self.device = device
         self.operand_dtype = operand_dtype
         self.weight_split = bool(weight_split)
+        self.ln_fold = _ln_fold()  # ESM_AMD_LN_FOLD at creation: a changed setting makes a new engine
         # ESM-1b / ESM-1v (esm_amd.esm1.ProteinBertModel) set these; ESM-2 leaves them at zero
         self.no_rope = int(getattr(model, "_engine_no_rope", 0))
         num_positions = int(getattr(model, "_engine_num_positions", 0))
@@ -172,6 +180,8 @@ class _Engine:
             model.alphabet_size, model.padding_idx, model.mask_idx, model.cls_idx, model.eos_idx,
             int(bool(model.token_dropout)), int(bool(model.prepend_bos)), int(bool(model.append_eos)),
             N.dtype_code(operand_dtype), self.no_rope, num_positions, ln_before, int(self.weight_split),
+            # the fold is asked for only where the library supports it (plain operands, head_dim <= 64); elsewhere "default"
+            self.ln_fold if (not self.weight_split and model.embed_dim // model.attention_heads <= 64) or self.ln_fold < 0 else 0,
         )
         self.handle = ctypes.c_void_p()
         with torch.cuda.device(device):
@@ -221,7 +231,8 @@ class _Engine:
         if fp == self.fingerprint:
             return
         stream = N.cur_stream()
-        for key, t in named:
+        # LayerNorm parameters first: with the LayerNorm fold the q/k/v and fc1 weights are folded with them at pack time
+        for key, t in sorted(named, key=lambda kt: 0 if "layer_norm" in kt[0] else 1):
             t = t.detach()
             if not t.is_contiguous():
                 t = t.contiguous()
@@ -286,7 +297,8 @@ class ESM2(nn.Module):
         odt = _operand_dtype_for(pdt)
         split = _weight_split()
         eng = self._engine
-        if eng is None or eng.device != device or eng.operand_dtype != odt or eng.weight_split != split:
+        if (eng is None or eng.device != device or eng.operand_dtype != odt or eng.weight_split != split
+                or eng.ln_fold != _ln_fold()):
             if eng is not None:
                 eng.close()
             eng = _Engine(self, device, odt, split)

@@ -25,7 +25,7 @@ class Config(ctypes.Structure):  # struct esmk_config
     _fields_ = [(n, ctypes.c_int32) for n in (
         "num_layers", "embed_dim", "num_heads", "ffn_dim", "vocab", "pad_idx", "mask_idx", "cls_idx", "eos_idx",
         "token_dropout", "prepend_bos", "append_eos", "operand_dtype", "no_rope", "num_positions", "ln_before",
-        "weight_split")]
+        "weight_split", "ln_fold")]
 
 
 def lib(path=None):
@@ -41,12 +41,13 @@ def _chk(rc):
         raise RuntimeError(lib().esmk_last_error().decode())
 
 
-def config_for(m, operand_dtype=torch.float16, weight_split=0):
+def config_for(m, operand_dtype=torch.float16, weight_split=0, ln_fold=0):
     """esmk_config from the attributes ESM2.__init__ sets (esm/model/esm2.py:24-38).  weight_split = 1: the engine's
-    f16x2 precision mode (split weights, 2x GEMM time, ~40 % lower error; esmk.h)."""
+    f16x2 precision mode (split weights, 2x GEMM time, ~40 % lower error; esmk.h).  ln_fold: 0 = the library's default,
+    1 / -1 = LayerNorm fold on / off (esmk.h)."""
     return Config(m.num_layers, m.embed_dim, m.attention_heads, 4 * m.embed_dim, m.alphabet_size, m.padding_idx,
                   m.mask_idx, m.cls_idx, m.eos_idx, int(bool(m.token_dropout)), int(bool(m.prepend_bos)),
-                  int(bool(m.append_eos)), _DTYPE[operand_dtype], 0, 0, 0, int(weight_split))
+                  int(bool(m.append_eos)), _DTYPE[operand_dtype], 0, 0, 0, int(weight_split), int(ln_fold))
 
 
 class Engine:
@@ -76,7 +77,8 @@ class Engine:
         fp = tuple((t.data_ptr(), t._version, t.dtype) for _, t in named)
         if fp == self.fingerprint:
             return
-        for k, t in named:
+        # LayerNorm parameters first: with the engine's LayerNorm fold (esmk.h) q/k/v and fc1 weights are folded with them
+        for k, t in sorted(named, key=lambda kt: 0 if "layer_norm" in kt[0] else 1):
             t = t.detach().contiguous()
             shape = (ctypes.c_int64 * t.dim())(*t.shape)
             _chk(lib().esmk_pack_weight(self.h, ctypes.c_void_p(self.packed.data_ptr()),

@@ -72,6 +72,13 @@ typedef struct esmk_config {
      * activations — the weight rounding, two thirds of the fp16-operand error of a 33-layer stack,
      * disappears at 2x the GEMM time.  Parameter image 2x larger.  0 = plain fp16 / bf16 operands. */
     int32_t weight_split;
+    /* LayerNorm fold (reference esm/modules.py:120-140, the two LayerNorm -> Linear pairs of a TransformerLayer): 1 = the
+     * q/k/v and fc1 weights are packed multiplied by the LayerNorm weight and row-centred, the residual GEMMs emit the
+     * operand-dtype rows and their statistics, and the standalone per-layer LayerNorm passes disappear (plain fp16 / bf16
+     * operands, head_dim <= 64; esmk_create fails otherwise); -1 = off; 0 = the library's default (environment
+     * ESMK_LN_FOLD=0|1 overrides it).  With the fold the LayerNorm weight and bias of a layer MUST be packed before
+     * that layer's q/k/v and fc1 weights (esmk_pack_weight fails otherwise; esmk_forward fails while a fold is stale). */
+    int32_t ln_fold;
 } esmk_config;
 
 const char* esmk_last_error(void);
@@ -245,7 +252,9 @@ int esmk_debug_gemm_impl(int impl, int variant);
  * no knob changes a result bit.  "resid_desync" (>= 0): start-up delay of every other XCD's workgroups in the residual
  * GEMMs (out-projection, fc2), as a fraction of one tile's main loop, which takes the HBM-bound read-modify-write
  * epilogues of the two halves of the chip out of lockstep (gemm9.hip; environment: ESMK_RESID_DESYNC);
- * "resid_desync_group": 0 = odd XCDs late, 1 = every other workgroup of each XCD, 2 = four phases. */
+ * "resid_desync_group": 0 = odd XCDs late, 1 = every other workgroup of each XCD, 2 = four phases.
+ * "attn_stagger" (>= 0): start-up delay, in shader cycles per wave slot, of the co-resident workgroups of the attention
+ * kernel (attention.hip; environment: ESMK_ATTN_STAGGER). */
 int esmk_debug_set(const char* key, double value);
 
 /* Fused q/k/v projection + scaling + rotary + head split (multihead_attention.py:256-284,
@@ -261,6 +270,30 @@ int esmk_op_qkv_rope(esmk_model* m, const void* a_dev, const void* wqkv_dev,
 int esmk_op_qkv_rope2(esmk_model* m, const void* a_dev, const void* wqkv_dev,
                       const float* bias_dev, void* q_out, void* k_out, void* vt_out, int B, int T,
                       int log2_domain, void* stream);
+
+/* LayerNorm fold (esmk_config::ln_fold) as single ops — the pieces esmk_forward chains per layer (modules.py:120-140):
+ * esmk_op_rowstats: x fp32 [rows,E] -> y[row][c] = T(x - mean) (row stride ldy, operand dtype), mean[row], rstd[row]
+ *   (eps 1e-5, biased variance: the statistics of ESM1bLayerNorm, modules.py:68-81);
+ * esmk_op_fold_weight: w [N,K] of the Linear that follows a LayerNorm(gamma, beta) -> dst[n][k] = T(w[n][k] gamma[k] -
+ *   mean_k(w[n][.] gamma[.])) (row stride ld), bias2[n] = sum_k w[n][k] beta[k];
+ * esmk_op_linear_ln, epilogue 2 (consumer): out = T(gelu(ln_rstd[m] * (a . w^T) + bias + bias2)), a = the rows of
+ *   rowstats / of a producer, w = a folded image;  epilogue 4 (producer): out fp32 [M,N] += a . w^T + bias, and
+ *   h16[m][n] = T(out_new - ln_mean[m]) (row stride ldh), ln_part[m][n / 128] = (sum, sum of squares) of out_new -
+ *   ln_mean[m] over the 128 columns (ln_parts >= ceil(N / 128) entries per row);
+ * esmk_op_ln_finalize: ln_part -> mean[row] += sum / E, rstd[row] = rsqrt(var + 1e-5);
+ * esmk_op_qkv_rope_ln: esmk_op_qkv_rope2 with folded wqkv and the rows' rstd (ln_rstd must be readable up to the next
+ *   multiple of 256 rows). */
+int esmk_op_rowstats(const float* x_dev, void* y_dev, float* mean_dev, float* rstd_dev, int rows, int E, int ldy,
+                     int operand_dtype, void* stream);
+int esmk_op_ln_finalize(const float* part_dev, float* mean_dev, float* rstd_dev, int rows, int parts, int E, void* stream);
+int esmk_op_fold_weight(const void* w_dev, int w_dtype, const float* gamma_dev, const float* beta_dev, void* dst_dev,
+                        int dst_dtype, float* bias2_dev, int N, int K, int ld, void* stream);
+int esmk_op_linear_ln(const void* a_dev, const void* w_dev, const float* bias_dev, const float* bias2_dev, void* out_dev,
+                      int M, int N, int K, int epilogue, int operand_dtype, const float* ln_rstd_dev, void* h16_dev, int ldh,
+                      float* ln_part_dev, int ln_parts, const float* ln_mean_dev, int half_m, void* stream);
+int esmk_op_qkv_rope_ln(esmk_model* m, const void* a_dev, const void* wqkv_dev, const float* bias_dev,
+                        const float* bias2_dev, const float* ln_rstd_dev, void* q_out, void* k_out, void* vt_out, int B, int T,
+                        int log2_domain, void* stream);
 
 /* softmax(q k^T + key_bias) v  (multihead_attention.py:357-394), flash style.
  * SCORE DOMAIN: q must carry log2(e) besides d^-1/2 (esmk_forward's QKV epilogue folds both into the q scale

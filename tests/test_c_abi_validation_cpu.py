@@ -162,4 +162,30 @@ def test_documented_config_struct_matches_header_and_binding():
     stub = open(os.path.join(root, "examples", "reference_binding", "_esmk.py")).read()
     m = re.search(r"_fields_\s*=\s*\[(.*?)\]\s*\n", stub, re.S)
     assert re.findall(r'"(\w+)"', m.group(1)) == native
-    assert ctypes.sizeof(N.EsmkConfig) == 4 * len(native) == 68
+    assert ctypes.sizeof(N.EsmkConfig) == 4 * len(native) == 72
+
+
+def test_ln_fold_validation_without_gpu():
+    """esmk_config.ln_fold: refused together with weight_split and for head_dim 128; with the fold a q/k/v or fc1 weight
+    packed before the layer's LayerNorm parameters fails before the library touches the device."""
+    h = ctypes.c_void_p()
+    f16 = N.dtype_code(torch.float16)
+    cfg = N.EsmkConfig(1, 128, 2, 512, 33, 1, 32, 0, 2, 1, 1, 1, f16, 0, 0, 0, 1, 1)
+    assert N.lib.esmk_create(ctypes.byref(cfg), ctypes.byref(h)) != 0 and "ln_fold" in err()
+    cfg = N.EsmkConfig(1, 256, 2, 1024, 33, 1, 32, 0, 2, 1, 1, 1, f16, 0, 0, 0, 0, 1)  # head_dim 128
+    assert N.lib.esmk_create(ctypes.byref(cfg), ctypes.byref(h)) != 0 and "ln_fold" in err()
+    cfg = N.EsmkConfig(1, 128, 2, 512, 33, 1, 32, 0, 2, 1, 1, 1, f16, 0, 0, 0, 0, 1)
+    assert N.lib.esmk_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+    try:
+        nb = ctypes.c_size_t()
+        assert N.lib.esmk_packed_bytes(h, ctypes.byref(nb)) == 0
+        shape = (ctypes.c_int64 * 2)(128, 128)
+        for key in (b"layers.0.self_attn.q_proj.weight", b"layers.0.self_attn.v_proj.weight", b"layers.0.fc1.weight"):
+            rc = N.lib.esmk_pack_weight(h, FAKE, nb.value, key, FAKE, 0, shape, 2, None)
+            assert rc != 0 and "LayerNorm" in err(), key
+    finally:
+        N.lib.esmk_destroy(h)
+    # the fold is off by request: the same keys are plain conversions (which would touch the device: not called here)
+    cfg = N.EsmkConfig(1, 128, 2, 512, 33, 1, 32, 0, 2, 1, 1, 1, f16, 0, 0, 0, 0, -1)
+    assert N.lib.esmk_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+    N.lib.esmk_destroy(h)

@@ -28,6 +28,16 @@ def set_impl(impl, var=0, desync=0.0, group=0):
     nat.check(nat.lib.esmk_debug_set(b"resid_desync_group", float(group)))
 
 
+def linear_ln_producer(a, w, bias, out, h16, part, mean, half_m=0):
+    """the LayerNorm-fold producer form of the residual GEMM (esmk_op_linear_ln, epilogue 4)"""
+    M, K = a.shape
+    Nn = w.shape[0]
+    nat.check(nat.lib.esmk_op_linear_ln(nat.ptr(a), nat.ptr(w), nat.ptr(bias), nat.ptr(None), nat.ptr(out), M, Nn, K, nat.EPI_RESID_F32,
+                                        nat.dtype_code(a.dtype), nat.ptr(None), nat.ptr(h16), h16.shape[1], nat.ptr(part), part.shape[1],
+                                        nat.ptr(mean), half_m, nat.cur_stream()))
+    return out
+
+
 def timeit(fn, iters):
     fn()
     torch.cuda.synchronize()
@@ -137,7 +147,8 @@ def main():
     dt = torch.float16
     cases = [("qk store", 2 * E, E, nat.EPI_STORE_T), ("v/out store", E, E, nat.EPI_STORE_T), ("out resid", E, E, nat.EPI_RESID_F32),
              ("fc1 store", F, E, nat.EPI_STORE_T), ("fc1 gelu", F, E, nat.EPI_GELU_T), ("fc2 store", E, F, nat.EPI_STORE_T),
-             ("fc2 resid", E, F, nat.EPI_RESID_F32), ("out store32", E, E, nat.EPI_STORE_F32), ("fc2 store32", E, F, nat.EPI_STORE_F32)]
+             ("fc2 resid", E, F, nat.EPI_RESID_F32), ("out store32", E, E, nat.EPI_STORE_F32), ("fc2 store32", E, F, nat.EPI_STORE_F32),
+             ("out gelu32", E, E, nat.EPI_GELU_F32), ("fc2 gelu32", E, F, nat.EPI_GELU_F32)]
     if args.cases:
         cases = [c for c in cases if any(k in c[0] for k in args.cases.split(","))]
     for name, N, K, epi in cases:
@@ -182,6 +193,21 @@ def main():
             print(f"{name:12s} desync arms bit-identical to the plain launch: {same}", flush=True)
             bad += 0 if same else 1
             del outs, x0
+        if epi == nat.EPI_RESID_F32 and not args.half:  # the LayerNorm-fold producer next to the plain residual epilogue
+            h16 = torch.zeros(M, N, dtype=dt, device="cuda")
+            part = torch.zeros(M, (N + 127) // 128, 2, device="cuda")
+            mean = torch.zeros(M, device="cuda")
+            set_impl(9, 0)
+            fn = lambda: linear_ln_producer(a, w, bias, out, h16, part, mean)
+            for dbg, tag in ((0, "LN-fold producer"), (1, "  no h16 stores"), (2, "  no statistics"), (4, "  no mean loads"), (7, "  none of them")):
+                nat.check(nat.lib.esmk_debug_set(b"lnf_dbg", float(dbg)))
+                ts = [timeit(fn, args.iters) for _ in range(args.rounds)]
+                loop, ep, seam, ghz = stamps(fn, min(32, (((M + 255) // 256) * ((N + 255) // 256)) // 256), K // 64)
+                ms = statistics.median(ts)
+                print(f"{name:12s} {tag:18s} {ms*1e3:8.1f} us (min {min(ts)*1e3:8.1f}) {flops/ms/1e9:7.1f} TFLOP/s | cycles/K-tile {loop:7.1f} "
+                      f"epilogue {ep:7.0f} seam {seam:6.0f} clock {ghz:4.2f} GHz", flush=True)
+            nat.check(nat.lib.esmk_debug_set(b"lnf_dbg", 0.0))
+            del h16, part, mean
         nt = ((M + 255) // 256) * ((N + 255) // 256)
         for n, impl, var, dsf, dsg in arms:
             set_impl(impl, var, dsf, dsg)

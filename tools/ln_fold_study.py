@@ -37,6 +37,20 @@ def folded_linear(x, gamma, beta, w, b):
     return rstd * (acc - mean * s) + (F.linear(beta[None, :], w)[0] + b)
 
 
+def folded_linear_centered(x, gamma, beta, w, b):
+    """The form the engine builds (round 4): the mean subtraction is folded into the weights as well —
+    W'' = gamma W - rowmean(gamma W), so that  sum_k x_k W''_nk = sum_k (x_k - mean) (gamma W)_nk  exactly in real
+    arithmetic — and the epilogue is ONE fma per element: y = rstd * (fp16(x) . fp16(W'')^T) + (W . beta + b).
+    What is left of the mean after rounding W'' is mean * sum_k (fp16(W'')_nk - W''_nk): ~ |mean| / std * 2^-12."""
+    rstd = torch.rsqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    wg = w * gamma[None, :]
+    wg = r16(wg - wg.mean(-1, keepdim=True))
+    return rstd * F.linear(r16(x), wg) + (F.linear(beta[None, :], w)[0] + b)
+
+
+FOLD = {1: folded_linear, 2: folded_linear_centered}
+
+
 def layer(sd, i, x, heads, fold, stats=None):
     p = f"layers.{i}."
     B, T, E = x.shape
@@ -45,7 +59,7 @@ def layer(sd, i, x, heads, fold, stats=None):
     g1, b1 = sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"]
     pa = p + "self_attn."
     if fold:
-        q, k, v = (folded_linear(x, g1, b1, sd[pa + n + ".weight"], sd[pa + n + ".bias"]) for n in ("q_proj", "k_proj", "v_proj"))
+        q, k, v = (FOLD[fold](x, g1, b1, sd[pa + n + ".weight"], sd[pa + n + ".bias"]) for n in ("q_proj", "k_proj", "v_proj"))
         if stats is not None:
             stats.append((x.abs().max().item(), (x.mean(-1).abs() / x.std(-1)).max().item()))
     else:
@@ -60,16 +74,16 @@ def layer(sd, i, x, heads, fold, stats=None):
     x = x + O._linear(ctx, sd[pa + "out_proj.weight"], sd[pa + "out_proj.bias"], inj)
     g2, b2 = sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"]
     if fold:
-        f = folded_linear(x, g2, b2, sd[p + "fc1.weight"], sd[p + "fc1.bias"])
+        f = FOLD[fold](x, g2, b2, sd[p + "fc1.weight"], sd[p + "fc1.bias"])
     else:
         f = O._linear(O.layer_norm(x, g2, b2), sd[p + "fc1.weight"], sd[p + "fc1.bias"], inj)
     return x + O._linear(O.gelu(f), sd[p + "fc2.weight"], sd[p + "fc2.bias"], inj)
 
 
 @torch.no_grad()
-def forward(sd, toks, L, heads, fold, stats=None):
+def forward(sd, toks, L, heads, fold, stats=None, offset=0.0):
     # no <mask> tokens / padding in the synthetic sample: token dropout is the constant rescale of esm2.py:86-92
-    x = F.embedding(toks, sd["embed_tokens.weight"]) * (1 - 0.15 * 0.8)
+    x = F.embedding(toks, sd["embed_tokens.weight"]) * (1 - 0.15 * 0.8) + offset
     for i in range(L):
         x = layer(sd, i, x, heads, fold, stats)
     return O.layer_norm(x, sd["emb_layer_norm_after.weight"], sd["emb_layer_norm_after.bias"])
@@ -81,6 +95,8 @@ def main():
     ap.add_argument("--T", type=int, default=128)
     ap.add_argument("--B", type=int, default=2)
     ap.add_argument("--seeds", type=int, default=2)
+    ap.add_argument("--offset", type=float, default=0.0, help="constant added to every channel of the embedding: a residual "
+                    "stream whose per-row mean is not small against its spread (stress for the folded mean subtraction)")
     a = ap.parse_args()
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     L, E, H = ESM2_DIMS[a.model]
@@ -90,12 +106,24 @@ def main():
         toks = synth_tokens(a.B, a.T, seed=100 + seed)
         ref = O.esm2_forward(sd, toks, L, H, repr_layers=[L])["representations"][L].double()
         rel = lambda t: (((t.double() - ref).abs().max() / ref.abs().max()).item(), ((t.double() - ref).norm() / ref.norm()).item())
-        plain = forward(sd, toks, L, H, fold=False)
+        if a.offset:  # the fp32 reference of the shifted stream
+            ref = forward(sd, toks, L, H, fold=False, offset=a.offset)  # fp16-operand run: only for the |x| statistics
+            inj = O.ALL_OPERANDS
+            O.ALL_OPERANDS = ()
+            ref = forward({**sd}, toks, L, H, fold=False, offset=a.offset).double() if False else None
+            O.ALL_OPERANDS = inj
+        plain = forward(sd, toks, L, H, fold=False, offset=a.offset)
         stats = []
-        fold = forward(sd, toks, L, H, fold=True, stats=stats)
-        (pm, pl), (fm, fl) = rel(plain), rel(fold)
-        print(f"seed {seed}: fp16-operand floor {pm:.2e} / {pl:.2e};  LayerNorm folded {fm:.2e} / {fl:.2e}  "
-              f"(x{fl / pl:.2f} in L2);  stream: max|x| {max(s[0] for s in stats):.1f}, max |mean|/std per row {max(s[1] for s in stats):.2f}")
+        fold = forward(sd, toks, L, H, fold=1, stats=stats, offset=a.offset)
+        foldc = forward(sd, toks, L, H, fold=2, offset=a.offset)
+        if a.offset:  # no oracle for the shifted stream: the folded forms against the plain fp16-operand run
+            d = lambda t: (((t.double() - plain.double()).abs().max() / plain.abs().max()).item(), ((t.double() - plain.double()).norm() / plain.double().norm()).item())
+            print(f"seed {seed} (offset {a.offset}): vs the plain fp16-operand run: folded {d(fold)[0]:.2e} / {d(fold)[1]:.2e}; centred fold {d(foldc)[0]:.2e} / {d(foldc)[1]:.2e};"
+                  f"  max |mean|/std per row {max(s[1] for s in stats):.2f}")
+            continue
+        (pm, pl), (fm, fl), (cm, cl) = rel(plain), rel(fold), rel(foldc)
+        print(f"seed {seed}: fp16-operand floor {pm:.2e} / {pl:.2e};  LayerNorm folded {fm:.2e} / {fl:.2e}  (x{fl / pl:.2f} in L2);  "
+              f"centred fold (1 fma) {cm:.2e} / {cl:.2e} (x{cl / pl:.2f});  stream: max|x| {max(s[0] for s in stats):.1f}, max |mean|/std per row {max(s[1] for s in stats):.2f}")
 
 
 if __name__ == "__main__":
