@@ -97,8 +97,16 @@ def default_writer_threads() -> int:
     container), most of it with the GIL released, so writer THREADS scale — up to a point: 277 / 558 / 1063 / 993 /
     912 files/s with 1 / 2 / 4 / 8 / 16 threads on an idle 8-core host, and 24 threads on the 256-thread GPU host
     were slower than 8 (the pickling parts hold the GIL: more threads, longer convoys).  440 files/s keep one
-    MI355X busy at L = 1022."""
-    return max(2, min(8, (os.cpu_count() or 4) // 2))
+    MI355X busy at L = 1022.  With 8 ranks on one host the limit is the kernel's page-cache write path, not this
+    process (~7 GB/s of new file pages per host whatever the file system; profiles/r4_extract_hosts.log): 4 threads per
+    rank wrote 1.44 M residues/s there, 8 threads 1.31 M, 16 threads 1.25 M — so several ranks on one host take 4."""
+    n = max(2, min(8, (os.cpu_count() or 4) // 2))
+    try:
+        if int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) >= 4:
+            n = min(n, 4)
+    except ValueError:
+        pass
+    return n
 
 
 class _Writer:
@@ -379,6 +387,10 @@ def create_parser():
                    help="accepted for command-line compatibility with scripts/extract.py and refused: the engine has "
                         "no CPU path")
     p.add_argument("--writer_threads", type=int, default=0, help="result-file writer threads (0 = from the host's cores)")
+    p.add_argument("--crc32", action="store_true",
+                   help="let torch.save compute the zip CRC32 of every record (the reference's files carry it; torch.load never "
+                        "checks it).  Default off: the checksum is 1.2 of the 3.3 ms a 5 MB per-token file costs "
+                        "(torch.serialization.set_crc32_options)")
     p.add_argument("--no_varlen", action="store_true",
                    help="always run padded batches (default: token-packed batches whenever they save >= 8 %% of the rows)")
     p.add_argument("--mean_matrix", type=pathlib.Path, default=None,
@@ -404,6 +416,8 @@ def main(argv=None):
     dist, rank, world, local_rank = init_ranks(world_env, "nccl")  # nccl == RCCL on ROCm
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if not args.crc32 and hasattr(torch.serialization, "set_crc32_options"):
+        torch.serialization.set_crc32_options(False)  # process wide: this process only writes result files
     model, alphabet = pretrained.load_model_and_alphabet(args.model_location)
     if isinstance(model, MSATransformer):  # scripts/extract.py:66-69
         raise ValueError("This script currently does not handle models with MSA input (MSA Transformer).")
