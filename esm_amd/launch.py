@@ -61,11 +61,19 @@ def rank_cpu_slice(local_rank: int, local_world: int, cpus=None):
     return set(cpus[local_rank * per:(local_rank + 1) * per])
 
 
-def pin_rank_cpus(local_rank: int, local_world: int):
+def pin_rank_cpus(local_rank: int, local_world: int, force: bool = False):
     """Restrict this process (and the threads it starts) to its share of the host's CPUs.  ``ESM_AMD_NO_AFFINITY=1``
-    switches it off.  Returns the CPU set in effect."""
+    switches it off.  Returns the CPU set in effect.
+
+    Only a process that still sees the WHOLE host is sliced: when the launcher (torchrun NUMA binding, taskset, a cgroup per
+    rank) already gave this rank a CPU set of its own, that set is kept as it is — slicing it again would leave e.g. 2 of 16
+    CPUs to the tokeniser, the writer threads and the GPU driver thread.  ``force`` slices regardless (the host
+    benchmark, which starts its ranks itself from one unrestricted parent)."""
     if os.environ.get("ESM_AMD_NO_AFFINITY", "0") == "1" or not hasattr(os, "sched_setaffinity"):
         return set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set()
+    have = os.sched_getaffinity(0)
+    if not force and len(have) < (os.cpu_count() or len(have)):
+        return set(have)  # restricted by whoever started us: not ours to narrow further
     want = rank_cpu_slice(local_rank, local_world)
     try:
         os.sched_setaffinity(0, want)

@@ -61,7 +61,12 @@ def contact_report(c, cr):
 
 
 def argmax_check(logits, ref_logits, mask=None):
-    err = (logits - ref_logits).abs().max().item()
+    """(raw argmax agreement, agreement wherever the reference's top-2 margin exceeds twice the logit error, that
+    error) over the positions of ``mask`` ONLY — pad positions hold whatever the pad rows computed (the reference
+    discards them, SURVEY §8 c), and an error taken over them (4.5e+1 on the padded 3B fixture) made the decided set
+    empty and the check vacuous."""
+    diff = (logits - ref_logits).abs()
+    err = (diff[mask] if mask is not None else diff).max().item()
     top2 = ref_logits.topk(2, dim=-1).values
     decided = (top2[..., 0] - top2[..., 1]) > 2 * err
     same = logits.argmax(-1) == ref_logits.argmax(-1)
@@ -69,6 +74,7 @@ def argmax_check(logits, ref_logits, mask=None):
         decided, same_m = decided & mask, same[mask]
     else:
         same_m = same
+    assert decided.sum().item() > 0, "no position with a decided argmax: the check would be vacuous"
     return same_m.float().mean().item(), bool(same[decided].all()), err
 
 
@@ -116,7 +122,7 @@ def _check_3b(model, name, mode="f16"):
                          contact_logit_rel=zrel, fused_vs_materialised=fperr)
     raw, decided_ok, lerr = argmax_check(out["logits"].float().cpu(), fix["logits"], nonpad)
     print(f"\n{name}: {report}; logits abs err {lerr:.2e}, argmax raw {raw:.4f}, decided ok {decided_ok}")
-    lrel = lerr / fix["logits"].abs().max().item()
+    lrel = lerr / fix["logits"][nonpad].abs().max().item()
     print(f"{name} [{mode}]: logits rel {lrel:.2e}")
     for b, r in report.items():
         if mode == "f16x2":
@@ -130,7 +136,12 @@ def _check_3b(model, name, mode="f16"):
             assert r["contact_logit_rel"] < 3e-3 and r["contact_prob"] < 1e-2, (b, r)
         assert r["fused_vs_materialised"] < 1e-4, (b, r)
     if mode == "f16x2":
-        assert lrel < 1e-3, lrel  # the contract on the logits, which plain fp16 operands miss (1.4e-3)
+        assert lrel < 1e-3, lrel  # the contract on the logits, which plain fp16 operands miss (1.1 - 1.5e-3)
+    else:
+        # plain fp16 operands: the logits carry the representation's error through one more LayerNorm and two GEMMs; a
+        # CPU study with the head in exact arithmetic still leaves 1.0 - 1.3e-3 (profiles/r4_parity_budget_study.log),
+        # i.e. 1e-3 on the logits is not reachable in this mode by any change to the head — bounded at 1.6e-3
+        assert lrel < 1.6e-3, lrel
     assert decided_ok and raw > 0.98
     return report, lrel, raw
 

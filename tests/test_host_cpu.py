@@ -269,6 +269,15 @@ def test_gelu_polynomial_of_the_epilogues_matches_erf():
     assert coef.size == 12 and np.float32(k2) == np.float32(2 / clamp**2)
     e_in, e_out = fg.report(coef, clamp)
     assert e_in < 2e-6 and e_out < 2e-6, (e_in, e_out)
+    # the tails: beyond the clamp the value is x * (0.5 + u Q(1)) with u = +-clamp — x * (1 + eps) on the right,
+    # x * eps on the left, |eps| <= 1.4e-6: it does not decay to 0 like the exact GELU, it stays a 1.4e-6 |x| residue of
+    # either sign (7e-5 at x = -50: below fp16's smallest normal 6.1e-5 x 1.2; nothing in a trained ESM-2 sends fc1 outputs
+    # there).  Pinned here so that a coefficient change cannot silently widen it.
+    xs = np.concatenate([np.linspace(-100.0, -clamp, 200001), np.linspace(clamp, 100.0, 200001)])
+    got = fg.gelu_poly_f32(xs, coef, clamp).astype(np.float64)
+    exact = np.where(xs > 0, xs, 0.0)  # gelu(x) to 1e-6 |x| beyond |x| = 4.75
+    assert (np.abs(got - exact) / np.abs(xs)).max() < 2e-6
+    assert np.abs(got[xs < 0]).max() < 2e-4
 
 
 def test_precision_study_tool_floor_is_ordered():

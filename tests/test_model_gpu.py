@@ -104,10 +104,16 @@ def test_engine_matches_reference_fixture(path):
     c, cr = out["contacts"].cpu(), fix["contacts"]
     assert c.shape == cr.shape
     perr, zerr, zrange = contact_errors(c, cr, with_range=True)
+    print(f"\n{os.path.basename(path)}: contact prob err {perr:.2e}, logit err {zerr:.2e} (range of the reference logits {zrange:.1f})")
     # the random regression (std 4 over L*H channels) amplifies the ~5e-3 score error of fp16 q,k; the 8M fixture
     # sums 120 channels (6 layers x 20 heads) and measures 5.2e-3.  Logits: the convention of the full-size tests,
     # error as a fraction of the range of the unsaturated reference logits (5.2 ... 15.8 on these fixtures)
-    assert perr < (8e-3 if d["L"] * d["H"] > 100 else 5e-3) and zerr < 3e-3 * zrange, (perr, zerr, zrange)
+    # Measured (round 4, unchanged since the 16x16x32 MFMAs of round 3; logit error / range): eosmid 8.0e-3 / 5.2, mid
+    # 1.46e-2 / 14.8, nopad 8.6e-3 / 10.2, tiny 8.8e-3 / 11.3, t6_8M_dims 3.38e-2 / 15.8.  The absolute 3e-2 bound of
+    # round 2 is kept for every fixture it held for; the 120-channel fixture, which measured 2.9e-2 then and
+    # 3.4e-2 since the MFMA shape changed the summation order, is held at 3.6e-2 AND 3e-3 of its logit range.
+    zmax = 3.6e-2 if d["L"] * d["H"] > 100 else 3e-2
+    assert perr < (8e-3 if d["L"] * d["H"] > 100 else 5e-3) and zerr < zmax and zerr < 3e-3 * zrange, (perr, zerr, zrange)
 
 
 def test_shape_pin_and_interior_pad():
@@ -160,13 +166,21 @@ def test_3b_dims_contacts_against_oracle():
     e = rel_err(out["representations"][36].cpu(), ref["representations"][36], nonpad)
     c, cr = out["contacts"].cpu(), ref["contacts"]
     # valid region of sequence 1 is [:59,:59]; sequence 0 is compared everywhere
-    p0, z0 = contact_errors(c[0], cr[0])
-    p1, z1 = contact_errors(c[1, :59, :59], cr[1, :59, :59])
-    print(f"\n3B-dims: repr rel {e:.2e}; contact prob err {p0:.2e}/{p1:.2e}, logit err {z0:.2e}/{z1:.2e}")
+    p0, z0, r0 = contact_errors(c[0], cr[0], with_range=True)
+    p1, z1, r1 = contact_errors(c[1, :59, :59], cr[1, :59, :59], with_range=True)
+    print(f"\n3B-dims: repr rel {e:.2e}; contact prob err {p0:.2e}/{p1:.2e}, logit err {z0:.2e}/{z1:.2e} of ranges {r0:.1f}/{r1:.1f}")
     l2, mx, bound = floor_referenced(out["representations"][36].cpu(), ref["representations"][36],
                                      floor["representations"][36], nonpad)
     print(f"3B-dims: repr L2 {l2:.2e}, max norm {mx:.2e} (bound {bound:.2e} = max(1e-3, 1.25 x floor))")
-    assert max(p0, p1) < 2e-2 and max(z0, z1) < 1e-1, (p0, p1, z0, z1)
+    # The contract, explicitly: 1e-3 in L2 — hard.  The max norm of this fixture measured 9.5e-4 with the
+    # 32x32x16 MFMAs of round 2 and 1.00e-3 since the 16x16x32 shape (another summation order; the emulated fp16-operand
+    # floor on the same inputs: 1.11e-3): it sits ON the contract, so besides the floor-referenced criterion a hard
+    # ceiling of 1.1e-3 keeps a real regression from hiding behind the floor.
+    assert l2 < REL_DEEP and mx < 1.1e-3, (l2, mx)
+    # contact logits relative to the range of the unsaturated reference logits (the convention of the full-size tests;
+    # was 1e-1 absolute).  Measured: 4.15e-2 / 4.85e-2 of ranges 16.0 / 16.0 = 2.6e-3 / 3.0e-3 (a 94-residue map under a
+    # 1440-channel regression; the T = 258 / 1022 fixtures of test_fullsize_gpu.py measure 1.2 - 1.8e-3)
+    assert max(p0, p1) < 2e-2 and z0 < 3.5e-3 * r0 and z1 < 3.5e-3 * r1, (p0, p1, z0, z1, r0, r1)
     # the same map without the [2,36,40,96,96] attention tensor (csrc/contacts.hip; 1440 channels, 40 heads)
     with torch.no_grad():
         fused = model.predict_contacts(toks.cuda()).cpu()
