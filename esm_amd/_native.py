@@ -42,7 +42,7 @@ class EsmkConfig(ctypes.Structure):
 class EsmkMsaConfig(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in (
         "num_layers", "embed_dim", "num_heads", "ffn_dim", "vocab", "pad_idx", "mask_idx", "cls_idx", "eos_idx",
-        "prepend_bos", "append_eos", "num_positions", "has_msa_position_embedding", "operand_dtype")]
+        "prepend_bos", "append_eos", "num_positions", "has_msa_position_embedding", "operand_dtype", "weight_split")]
 
 
 class EsmkProfileEntry(ctypes.Structure):

@@ -370,21 +370,21 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
             if (starts_with(sub, "row_self_attention.")) { a = &o.row; sub += 19; }
             else if (starts_with(sub, "column_self_attention.")) { a = &o.col; sub += 22; }
             if (a) {
-                if (!strcmp(sub, "layer.q_proj.weight")) return put(a->wqkv, op, E * E);
-                if (!strcmp(sub, "layer.k_proj.weight")) return put(a->wqkv + E * E * os, op, E * E);
-                if (!strcmp(sub, "layer.v_proj.weight")) return put(a->wqkv + 2 * E * E * os, op, E * E);
+                if (!strcmp(sub, "layer.q_proj.weight")) return putw(a->wqkv, E, E, E, 0, 0);
+                if (!strcmp(sub, "layer.k_proj.weight")) return putw(a->wqkv + E * E * os * ws, E, E, E, 0, 0);
+                if (!strcmp(sub, "layer.v_proj.weight")) return putw(a->wqkv + 2 * E * E * os * ws, E, E, E, 0, 0);
                 if (!strcmp(sub, "layer.q_proj.bias")) return put(a->bqkv, ESMK_DT_F32, E);
                 if (!strcmp(sub, "layer.k_proj.bias")) return put(a->bqkv + E * 4, ESMK_DT_F32, E);
                 if (!strcmp(sub, "layer.v_proj.bias")) return put(a->bqkv + 2 * E * 4, ESMK_DT_F32, E);
-                if (!strcmp(sub, "layer.out_proj.weight")) return put(a->wo, op, E * E);
+                if (!strcmp(sub, "layer.out_proj.weight")) return putw(a->wo, E, E, E, 0, 0);
                 if (!strcmp(sub, "layer.out_proj.bias")) return put(a->bo, ESMK_DT_F32, E);
                 if (!strcmp(sub, "layer_norm.weight")) return put(a->lng, ESMK_DT_F32, E);
                 if (!strcmp(sub, "layer_norm.bias")) return put(a->lnb, ESMK_DT_F32, E);
                 return 0;
             }
-            if (!strcmp(sub, "feed_forward_layer.layer.fc1.weight")) return put(o.w1, op, F * E);
+            if (!strcmp(sub, "feed_forward_layer.layer.fc1.weight")) return putw(o.w1, F, E, E, 0, 0);
             if (!strcmp(sub, "feed_forward_layer.layer.fc1.bias")) return put(o.b1, ESMK_DT_F32, F);
-            if (!strcmp(sub, "feed_forward_layer.layer.fc2.weight")) return put(o.w2, op, E * F);
+            if (!strcmp(sub, "feed_forward_layer.layer.fc2.weight")) return putw(o.w2, E, F, F, 0, 0);
             if (!strcmp(sub, "feed_forward_layer.layer.fc2.bias")) return put(o.b2, ESMK_DT_F32, E);
             if (!strcmp(sub, "feed_forward_layer.layer_norm.weight")) return put(o.flng, ESMK_DT_F32, E);
             if (!strcmp(sub, "feed_forward_layer.layer_norm.bias")) return put(o.flnb, ESMK_DT_F32, E);

@@ -16,6 +16,7 @@ namespace esmk_host {
 void plan_packed_msa(esmk_model* m) {
     const size_t os = op_size(m->cfg.operand_dtype);
     const size_t E = m->E, F = m->F, V = m->V;
+    const size_t ws = m->cfg.weight_split ? 2 : 1;  // f16x2: every layer matrix as [rows, 2 cols] (hi | lo K tiles)
     Carve c;
     m->embed_f32 = c.take(V * E * 4);
     m->embed_op = c.take(V * E * os);
@@ -26,6 +27,7 @@ void plan_packed_msa(esmk_model* m) {
     m->fin_g = c.take(E * 4);
     m->fin_b = c.take(E * 4);
     m->lm_w = c.take(E * E * os);
+    m->lm_w32 = c.take(ws == 2 ? E * E * 4 : 0);
     m->lm_b = c.take(E * 4);
     m->lm_lng = c.take(E * 4);
     m->lm_lnb = c.take(E * 4);
@@ -34,9 +36,9 @@ void plan_packed_msa(esmk_model* m) {
     m->ct_b = c.take(4);
     m->mlayer.resize(m->L);
     auto attn = [&](AttnOff& a) {
-        a.wqkv = c.take(3 * E * E * os);
+        a.wqkv = c.take(3 * E * E * os * ws);
         a.bqkv = c.take(3 * E * 4);
-        a.wo = c.take(E * E * os);
+        a.wo = c.take(E * E * os * ws);
         a.bo = c.take(E * 4);
         a.lng = c.take(E * 4);
         a.lnb = c.take(E * 4);
@@ -45,9 +47,9 @@ void plan_packed_msa(esmk_model* m) {
         MsaLayerOff& o = m->mlayer[l];
         attn(o.row);
         attn(o.col);
-        o.w1 = c.take(F * E * os);
+        o.w1 = c.take(F * E * os * ws);
         o.b1 = c.take(F * 4);
-        o.w2 = c.take(E * F * os);
+        o.w2 = c.take(E * F * os * ws);
         o.b2 = c.take(E * 4);
         o.flng = c.take(E * 4);
         o.flnb = c.take(E * 4);
@@ -128,6 +130,8 @@ int esmk_msa_create(const esmk_msa_config* cfg, esmk_model** out) {
         return fail("esmk_msa_create: embed_dim and ffn_dim must be multiples of 64");
     if (cfg->operand_dtype != ESMK_F16 && cfg->operand_dtype != ESMK_BF16)
         return fail("esmk_msa_create: operand_dtype must be ESMK_F16 or ESMK_BF16");
+    if (cfg->weight_split != 0 && cfg->operand_dtype != ESMK_F16)
+        return fail("esmk_msa_create: weight_split (precision mode f16x2) needs operand_dtype ESMK_F16");
     esmk_model* m = new esmk_model();
     memset(&m->cfg, 0, sizeof(m->cfg));
     m->cfg.num_layers = cfg->num_layers;
@@ -142,6 +146,7 @@ int esmk_msa_create(const esmk_msa_config* cfg, esmk_model** out) {
     m->cfg.prepend_bos = cfg->prepend_bos;
     m->cfg.append_eos = cfg->append_eos;
     m->cfg.operand_dtype = cfg->operand_dtype;
+    m->cfg.weight_split = cfg->weight_split != 0;
     m->L = cfg->num_layers;
     m->E = cfg->embed_dim;
     m->H = cfg->num_heads;
@@ -233,6 +238,20 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
         ESMK_TRY(launch_gemm(a, epi, op, st));
         return 0;
     };
+    // a GEMM against a weight matrix of the layer stack: with split weights (f16x2) the same kernel runs over
+    // the [N, 2K] hi | lo image, the activations' K tile kt / 2 meeting W_hi (kt even) and W_lo (kt odd)
+    const int wsf = m->cfg.weight_split ? 2 : 1;
+    auto wgemm = [&](int cls, GemmArgs a, int epi, double out_bytes_per_elem) -> int {
+        if (wsf == 1) return gemm(cls, a, epi, out_bytes_per_elem);
+        const double fl = 2.0 * a.M * (double)a.N * a.K;
+        const double by = ((double)a.M * a.K + 2.0 * a.N * a.K) * os + (double)a.M * a.N * out_bytes_per_elem;
+        a.a_row_bytes = (long long)a.K * (long long)os;
+        a.a_kt_repeat = 1;
+        a.K *= 2;
+        ProfScope ps(m, st, cls, fl, by);
+        ESMK_TRY(launch_gemm(a, epi, op, st));
+        return 0;
+    };
     auto lnorm = [&](const float* in, size_t go, size_t bo, void* y, float* y32, LnExtra ex) -> int {
         ProfScope ps(m, st, PC_LAYERNORM, 8 * NE, NE * (4 + (y ? os : 0) + (y32 ? 4 : 0)));
         ESMK_TRY(launch_layernorm_ex(in, (const float*)(pk + go), (const float*)(pk + bo), y, y32, N, E, op, ex, st));
@@ -243,7 +262,7 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
         const char* e = getenv("ESMK_QKV_FORK");
         return e != nullptr && atoi(e) != 0;
     }();
-    const bool fork_v = env_fork && !m->prof_on;
+    const bool fork_v = env_fork && !m->prof_on && !m->cfg.weight_split;
     if (fork_v && !m->side_stream) {
         ESMK_TRY(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
         ESMK_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
@@ -286,7 +305,7 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
         g.row_keep = row_keep;
         GemmArgs gv = g;
         gv.row_keep = nullptr;
-        gv.W = pk + a.wqkv + (size_t)2 * E * E * os;
+        gv.W = pk + a.wqkv + (size_t)2 * E * E * os * wsf;
         gv.bias = (const float*)(pk + a.bqkv) + 2 * E;
         gv.N = E;
         gv.vt_rows = vt_rows;
@@ -299,8 +318,8 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
             ESMK_TRY(hipStreamWaitEvent(st, m->ev_join, 0));
             return 0;
         }
-        if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;
-        return gemm(PC_GEMM_QKV, gv, EPI_V_T, os);
+        if (wgemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;
+        return wgemm(PC_GEMM_QKV, gv, EPI_V_T, os);
     };
     auto out_proj = [&](const AttnOff& a, int map_R, int map_C) -> int {
         GemmArgs g;
@@ -313,7 +332,7 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
         g.K = E;
         g.rowmap_R = map_R;
         g.rowmap_C = map_C;
-        return gemm(PC_GEMM_OUT, g, EPI_RESID_F32, 8);
+        return wgemm(PC_GEMM_OUT, g, EPI_RESID_F32, 8);
     };
 
     for (int l = 0; l < L; ++l) {
@@ -409,7 +428,7 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
             g.M = N;
             g.N = F;
             g.K = E;
-            if (gemm(PC_GEMM_FC1, g, EPI_GELU_T, os)) return 1;
+            if (wgemm(PC_GEMM_FC1, g, EPI_GELU_T, os)) return 1;
             g = GemmArgs();
             g.A = ffn;
             g.W = pk + o.w2;
@@ -418,7 +437,7 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
             g.M = N;
             g.N = E;
             g.K = F;
-            if (gemm(PC_GEMM_FC2, g, EPI_RESID_F32, 8)) return 1;
+            if (wgemm(PC_GEMM_FC2, g, EPI_RESID_F32, 8)) return 1;
         }
         if (l + 1 < L && repr_copy(l + 1, x)) return 1;  // msa_transformer.py:197-198
     }
@@ -437,7 +456,21 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
             if (repr_layers[i] == L && repr_out_dev[i] != rep_last)
                 ESMK_TRY(launch_copy_f32(rep_last, (float*)repr_out_dev[i], (size_t)N * E, st));
     }
-    if (want_logits) {  // modules.py:308-314
+    if (want_logits && m->cfg.weight_split && E % 32 == 0) {
+        // f16x2: the head (modules.py:308-314) in fp32 on the exact-fp32 MFMA path, as in esmk_forward
+        float* a32 = rep_last != nullptr ? rep_last : g32;
+        if (a32 == g32 && lnorm(x, m->fin_g, m->fin_b, nullptr, g32, LnExtra())) return 1;
+        {
+            ProfScope ps(m, st, PC_LM_DENSE, 2.0 * N * (double)E * E, (2.0 * NE + (double)E * E) * 4);
+            ESMK_TRY(launch_gemm32(a32, E, (const float*)(pk + m->lm_w32), (const float*)(pk + m->lm_b), x, E, N, E, E, true, st));
+        }
+        if (lnorm(x, m->lm_lng, m->lm_lnb, nullptr, g32, LnExtra())) return 1;  // x (the residual stream) is dead: dense output
+        {
+            ProfScope ps(m, st, PC_LM_LOGITS, 2.0 * N * (double)E * m->V, (NE + (double)m->V * E + (double)N * m->V) * 4);
+            ESMK_TRY(launch_gemm32(g32, E, (const float*)(pk + m->embed_f32), (const float*)(pk + m->lm_bias),
+                                   (float*)logits_out_dev, m->V, N, m->V, E, false, st));
+        }
+    } else if (want_logits) {  // modules.py:308-314
         GemmArgs g;
         g.A = h;
         g.W = pk + m->lm_w;

@@ -94,7 +94,7 @@ def _native_lowp(param_dtype, operand_dtype):
 def _weight_split():
     """``ESM_AMD_OPERAND=f16x2``: precision mode with split weights (W = W_hi + W_lo, both fp16, two MFMA passes per
     layer GEMM): removes the weight rounding — two thirds of the fp16-operand error of a deep stack — at 2x the GEMM
-    time.  ESM-2 / ESM-1b engines only (the MSA Transformer ignores it and runs plain fp16)."""
+    time.  ESM-2, ESM-1b and (since round 4) the MSA Transformer engine."""
     return os.environ.get("ESM_AMD_OPERAND", "").lower() in ("f16x2", "fp16x2")
 
 

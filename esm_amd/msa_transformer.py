@@ -18,7 +18,7 @@ import re
 import torch
 import torch.nn as nn
 
-from .esm2 import (ContactPredictionHead, RobertaLMHead, _Container, _operand_dtype_for, live_tensors,
+from .esm2 import (ContactPredictionHead, RobertaLMHead, _Container, _operand_dtype_for, _weight_split, live_tensors,
                    warn_if_grad_expected)
 
 _AXIS = re.compile(r"row|column")
@@ -74,16 +74,17 @@ class LearnedPositionalEmbedding(nn.Embedding):
 
 
 class _MsaEngine:
-    def __init__(self, model, device, operand_dtype):
+    def __init__(self, model, device, operand_dtype, weight_split=False):
         from . import _native as N
 
         self.N, self.device, self.operand_dtype = N, device, operand_dtype
+        self.weight_split = bool(weight_split)  # ESM_AMD_OPERAND=f16x2 (esmk_msa_config.weight_split)
         a = model.args
         cfg = N.EsmkMsaConfig(
             a.layers, a.embed_dim, a.attention_heads, a.ffn_embed_dim, model.alphabet_size, model.padding_idx,
             model.mask_idx, model.cls_idx, model.eos_idx if model.eos_idx is not None else -1,
             int(bool(model.prepend_bos)), int(bool(model.append_eos)), model.embed_positions.weight.shape[0],
-            int(model.msa_position_embedding is not None), N.dtype_code(operand_dtype))
+            int(model.msa_position_embedding is not None), N.dtype_code(operand_dtype), int(self.weight_split))
         self.handle = ctypes.c_void_p()
         with torch.cuda.device(device):
             N.check(N.lib.esmk_msa_create(ctypes.byref(cfg), ctypes.byref(self.handle)))
@@ -190,11 +191,12 @@ class MSATransformer(nn.Module):
 
     def _get_engine(self, device):
         odt = _operand_dtype_for(self.embed_tokens.weight.dtype)
+        split = _weight_split()
         eng = self._engine
-        if eng is None or eng.device != device or eng.operand_dtype != odt:
+        if eng is None or eng.device != device or eng.operand_dtype != odt or eng.weight_split != split:
             if eng is not None:
                 eng.close()
-            eng = _MsaEngine(self, device, odt)
+            eng = _MsaEngine(self, device, odt, split)
             object.__setattr__(self, "_engine", eng)
         return eng
 

@@ -250,6 +250,34 @@ def test_config5_msa_full_size_against_reference_fixture(name):
     assert r["contacts_prob"] < b["contacts_prob"] and r["contacts_logit_rel"] < b["contacts_logit_rel"], r
 
 
+@pytest.mark.gpu
+def test_config5_msa_full_size_split_weight_mode():
+    """Config 5 with ESM_AMD_OPERAND=f16x2 (round 4: the MSA engine takes the split-weight mode): against the calibrated
+    full-size reference fixture the representation error falls well under the plain mode's (5.2e-4 in L2, 6.1e-4 max)
+    and the logits come inside 1e-3 with margin (plain: 9.2e-4 ... 9.8e-4)."""
+    name = "msa1b_config5_g1"
+    fix = fixture(name)
+    L = fix["dims"]["L"]
+    model, _, toks = _msa_model_and_tokens(fix)
+    model = model.cuda()
+    model.return_col_attentions = False
+    old = os.environ.get("ESM_AMD_OPERAND")
+    os.environ["ESM_AMD_OPERAND"] = "f16x2"
+    try:
+        with torch.no_grad():
+            out = model(toks.cuda(), repr_layers=[L], return_contacts=True)
+    finally:
+        if old is None:
+            os.environ.pop("ESM_AMD_OPERAND", None)
+        else:
+            os.environ["ESM_AMD_OPERAND"] = old
+    got = GEN.slim_msa(out, L)
+    r = _msa_compare(got, fix, f"{name} [f16x2]: HIP engine vs reference fixture")
+    assert r["repr_row0_l2"] < 4.2e-4 and r["repr_sub_l2"] < 4.2e-4, r
+    assert r["repr_row0_max"] < 5.5e-4 and r["repr_sub_max"] < 5.5e-4, r
+    assert r["logits_row0"] < 8e-4 and r["argmax_decided_ok"], r
+
+
 # ------------------------------------------------------------------------------------------------------------
 # CPU: the oracle against the same full-size fixtures
 # ------------------------------------------------------------------------------------------------------------

@@ -90,6 +90,39 @@ def test_msa_engine_matches_oracle_at_100M_dims(B, R, C, pads):
     assert (out["contacts"].cpu() - ref["contacts"]).abs().max().item() < (5e-3 if R <= 32 else 8e-3)
 
 
+def test_msa_split_weight_mode():
+    """ESM_AMD_OPERAND=f16x2 on the MSA Transformer (esmk_msa_config.weight_split; round 4): every weight matrix of the
+    axial layers as W_hi + W_lo, the LM head in fp32 — the weight rounding, the largest single share of the fp16-operand
+    error, is gone: the error against the oracle must drop clearly below the plain mode's on the same inputs."""
+    L, E, H, F = 4, 768, 12, 3072
+    model, sd = build(L, E, H, F, seed=33)
+    toks = synth_msa_tokens(1, 32, 257, seed=4)
+    toks[0, :, 250:] = 1
+    ref = msa_forward(sd, toks, L, H, repr_layers=[L], return_contacts=True)
+    errs = {}
+    old = os.environ.get("ESM_AMD_OPERAND")
+    try:
+        for mode in ("f16", "f16x2"):
+            os.environ["ESM_AMD_OPERAND"] = mode
+            with torch.no_grad():
+                out = model(toks.cuda(), repr_layers=[L], return_contacts=True)
+            d = out["representations"][L].cpu().double() - ref["representations"][L].double()
+            errs[mode] = dict(repr_max=rel_err(out["representations"][L].cpu(), ref["representations"][L]),
+                              repr_l2=(d.norm() / ref["representations"][L].double().norm()).item(),
+                              logits=rel_err(out["logits"].cpu(), ref["logits"]),
+                              row_maps=(out["row_attentions"].cpu() - ref["row_attentions"]).abs().max().item(),
+                              contacts=(out["contacts"].cpu() - ref["contacts"]).abs().max().item())
+    finally:
+        if old is None:
+            os.environ.pop("ESM_AMD_OPERAND", None)
+        else:
+            os.environ["ESM_AMD_OPERAND"] = old
+    print(f"MSA 4 x 768, (1, 32, 257): {errs}")
+    assert errs["f16x2"]["repr_l2"] < 0.8 * errs["f16"]["repr_l2"], errs
+    assert errs["f16x2"]["logits"] < 0.8 * errs["f16"]["logits"], errs
+    assert errs["f16x2"]["repr_max"] < REL and errs["f16x2"]["logits"] < REL, errs
+
+
 def test_msa_config5_full_size_properties():
     """BASELINE config 5: esm_msa1b_t12_100M dimensions, one 128 x 513 MSA.  The CPU oracle needs minutes at this
     size, so the full-size run is checked through size-independent properties: finite outputs, row attention rows
