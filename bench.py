@@ -127,6 +127,7 @@ def protocol_test(args):
                           "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
                           "value": round(world * args.batch * args.seq_len * args.steps / elapsed, 1),
                           "scaling": "weak", "per_rank_ms_per_step": list(PER_RANK_MS),
+                          "config": {"workload": "protocol-test", "ln_fold": os.environ.get("ESM_AMD_LN_FOLD", "library default (off)")},
                           "backend": dist.get_backend() if dist is not None else None,
                           "launched_by": os.environ.get("ESM_AMD_BENCH_LAUNCH", "external-or-single")}), flush=True)
     finish(dist)
@@ -215,7 +216,8 @@ def base_result(args, world, metric, value, elapsed, workload, extra_cfg):
         "metric": metric, "value": round(value, 1), "unit": "residues/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": getattr(args, "scaling", "weak"), "vs_baseline": None, "dtype": operand_name(), "data": "synthetic",
-        "config": {"workload": workload, "sharding": f"dp{world} (no data-path collective)", **extra_cfg},
+        "config": {"workload": workload, "sharding": f"dp{world} (no data-path collective)",
+                   "ln_fold": os.environ.get("ESM_AMD_LN_FOLD", "library default (off)"), **extra_cfg},
         "host_cores": os.cpu_count(), "per_rank_ms_per_step": list(PER_RANK_MS),
     }
 
@@ -380,6 +382,11 @@ SECONDARY = [  # --quick-baseline: the children's own CPU-oracle sample (parity 
     ("msa1b", ["--workload", "msa1b", "--quick-baseline"], 120),
     ("extract_650m", ["--workload", "extract_650m", "--steps", "8", "--warmup", "2", "--quick-baseline"], 150),
     ("esm2_3b_contacts", ["--workload", "esm2_3b_contacts", "--steps", "4", "--quick-baseline"], 200),
+    # the reference script's default token budget (scripts/extract.py:36: 4096 tokens = 4 sequences of L = 1022), plain and
+    # with the LayerNorm fold (the fold pays at small batches)
+    ("esm2_650m_b4", ["--workload", "esm2_650m", "--batch", "4", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-secondary"], 60),
+    ("esm2_650m_b4_ln_fold", ["--workload", "esm2_650m", "--batch", "4", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                              "--no-secondary", "--ln-fold", "1"], 60),
 ]
 T_PROCESS_START = time.perf_counter()
 SECONDARY_BUDGET_S = 180.0  # the default run, children included, ends within ~3 minutes of its start
@@ -683,6 +690,9 @@ def main():
                          "child runs, ~2 min) as `secondary_workloads`; --no-cpu-baseline implies it")
     ap.add_argument("--out-dir", default=None, help="extract_650m: directory (file system) the result files go to")
     ap.add_argument("--writer-threads", type=int, default=0, help="extract_650m: writer threads (0 = from host cores)")
+    ap.add_argument("--ln-fold", type=int, choices=[0, 1], default=None,
+                    help="LayerNorm fold of the engine (esmk_config.ln_fold, DESIGN.md 4.8): 1 = the per-layer LayerNorm passes "
+                         "become GEMM epilogue work (faster at small batches, slower at B = 64), 0 = off (the library default)")
     ap.add_argument("--operand", choices=["f16", "bf16", "f16x2"], default=None,
                     help="MFMA operand type (default f16; bf16 is ~4 %% faster at ~7e-3 relative error; f16x2 = fp16 with "
                          "split weights W = W_hi + W_lo: 2x GEMM time, ~40 %% lower error — the precision mode with "
@@ -699,6 +709,8 @@ def main():
 
     if args.operand:
         os.environ["ESM_AMD_OPERAND"] = args.operand
+    if args.ln_fold is not None:
+        os.environ["ESM_AMD_LN_FOLD"] = str(args.ln_fold)
     if (args.gpus > 1 or args.spawn) and not under_launcher():
         os.environ["ESM_AMD_BENCH_LAUNCH"] = "self-spawned"
         raise SystemExit(relaunch(args.gpus, os.path.abspath(__file__), sys.argv[1:]))

@@ -774,6 +774,8 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
         const int m_base = tmi * TM + wr * WRM, n_base = tni * 256 + wc * 128;
         stamp(it, 0);
         ktile(true);
+        // (a `.p2align 6` in front of this loop changed nothing, for the fast and the slow instantiations alike:
+        // profiles/r4_ln_fold_ablation.log)
 #pragma unroll 1
         for (int kt = 1; kt < nk; ++kt) ktile(false);
         stamp(it, 1);

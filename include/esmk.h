@@ -152,7 +152,7 @@ typedef struct esmk_msa_config {
     int32_t num_positions;               /* rows of embed_positions.weight = max_positions + pad_idx + 1 */
     int32_t has_msa_position_embedding;  /* args.embed_positions_msa (msa_transformer.py:104-112) */
     int32_t operand_dtype;               /* ESMK_F16 or ESMK_BF16 */
-    int32_t weight_split;                /* 1: precision mode f16x2 as in esmk_config (operand_dtype ESMK_F16): every weight
+    int32_t weight_split;                /* 1: precision mode f16x2 (see esmk_config::weight_split; operand_dtype ESMK_F16): every weight
                                             matrix of the axial layers as W_hi + W_lo, the LM head on the fp32 MFMA path */
 } esmk_msa_config;
 

@@ -135,7 +135,8 @@ def test_secondary_workloads_glue(monkeypatch):
     import time as _t
 
     out = bench.secondary_workloads(extra=["--protocol-test"], budget_end=_t.perf_counter() + 1000)
-    assert list(out) == ["msa1b", "extract_650m", "esm2_3b_contacts"]
+    assert list(out) == ["msa1b", "extract_650m", "esm2_3b_contacts", "esm2_650m_b4", "esm2_650m_b4_ln_fold"]
+    assert out["esm2_650m_b4_ln_fold"]["config"]["ln_fold"] == "1" and out["esm2_650m_b4"]["config"]["ln_fold"] != "1"
     for name, r in out.items():
         assert "error" not in r, (name, r)
         assert r["metric"].startswith("protocol-test") and r["ms_per_step"] >= 4.5 and r["wall_s"] > 0
