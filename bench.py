@@ -47,9 +47,9 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0        # spec; 6.29 TB/s is the measured copy ceiling
 HBM_ACHIEVABLE_GBS = 6300.0
-PMC_SUMMARY = {"esm2_650m": os.path.join(ROOT, "profiles", "r3_pmc_summary.json"),
-               "msa1b": os.path.join(ROOT, "profiles", "r3_pmc_summary_msa1b.json"),
-               "esm2_3b_contacts": os.path.join(ROOT, "profiles", "r3_pmc_summary_esm2_3b_contacts.json")}
+PMC_SUMMARY = {"esm2_650m": os.path.join(ROOT, "profiles", "r4_pmc_summary.json"),
+               "msa1b": os.path.join(ROOT, "profiles", "r4_pmc_summary_msa1b.json"),
+               "esm2_3b_contacts": os.path.join(ROOT, "profiles", "r4_pmc_summary_esm2_3b_contacts.json")}
 
 
 def argmax_report(logits, ref_logits):
@@ -165,7 +165,7 @@ PMC_CLASS = {"gemm_qkv_rope": "gemm_qkv_rope(qk)"}
 
 def pmc_traffic(kernel_class, src_hash, workload="esm2_650m"):
     """HBM bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes of that workload (tools/
-    profile_bench.sh -> profiles/r3_pmc_summary*.json; FETCH_SIZE doubled as the microarch guide prescribes for
+    profile_bench.sh -> profiles/r4_pmc_summary*.json; FETCH_SIZE doubled as the microarch guide prescribes for
     gfx950).  The summary records the source hash of the library it profiled: a different build -> null (never a
     stale number)."""
     try:
