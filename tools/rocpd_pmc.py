@@ -4,6 +4,9 @@ import re, sqlite3, sys
 from collections import defaultdict
 
 def short(n):
+    m = re.search(r"(gemm9_kernel)I(DF16_|DF16b)((?:L[ib]\d+E)+)E", n)  # every template argument: EPI, VAR, HM, LNF
+    if m:
+        return "gemm9_kernel<" + ("f16" if m.group(2) == "DF16_" else "bf16") + "," + ",".join(re.findall(r"L[ib](\d+)E", m.group(3))) + ">"
     m = re.search(r"(gemm8_kernel|gemm9_kernel|gemm32_kernel|gemm256_kernel|gemm64_kernel|attn_fwd_kernel|attn_probs_kernel|layernorm_kernel)I([A-Za-z0-9_]*?)E", n)
     if m:
         return m.group(1) + "<" + m.group(2).replace("DF16_", "f16,").replace("DF16b", "bf16,").replace("Li", "") + ">"
