@@ -124,9 +124,15 @@ ESMK_DEV void epilogue8m(const GemmArgs& p, f32x4 (&acc)[NJT][NMI], int nj0, int
                     const f32x4& a = acc[nj0 + nj][2 * i + mi2];
                     if constexpr (LNF) {
                         const f32x4& rs = rs4[mi2];
+                        float x0 = __builtin_fmaf(a[0], rs[0], bv), x1 = __builtin_fmaf(a[1], rs[1], bv);
+                        float x2 = __builtin_fmaf(a[2], rs[2], bv), x3 = __builtin_fmaf(a[3], rs[3], bv);
+                        // The fp32 results go through an opaque barrier before the conversion: left alone the compiler
+                        // turns elements 0 and 3 into v_fma_mixlo_f16 (one rounding, fp32 product straight to fp16) and
+                        // keeps 1 and 2 as v_pk_fma_f32 + v_cvt_pk_f16_f32 (two roundings), so the fp16 value of a token
+                        // depended on its row index modulo 4 and a padded batch differed from the packed one by an ulp.
+                        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
                         *reinterpret_cast<V4*>(wl + dv * 64 + ((chunk ^ ((dv >> 1) & 3)) << 4) + 8 * half) =
-                            pack4_<T>(__builtin_fmaf(a[0], rs[0], bv), __builtin_fmaf(a[1], rs[1], bv), __builtin_fmaf(a[2], rs[2], bv),
-                                      __builtin_fmaf(a[3], rs[3], bv));
+                            pack4_<T>(x0, x1, x2, x3);
                     } else
                     *reinterpret_cast<V4*>(wl + dv * 64 + ((chunk ^ ((dv >> 1) & 3)) << 4) + 8 * half) =
                         pack4_<T>(a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv);

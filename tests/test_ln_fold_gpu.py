@@ -161,6 +161,43 @@ def test_qkv_chain_against_unfolded_ops():
         assert err < 3e-3, (name, err)
 
 
+@pytest.mark.parametrize("offset", [1, 2, 3, 5])
+def test_folded_v_bits_do_not_depend_on_row_offset(offset):
+    """The folded projection of a token must not depend on the row of the batch it sits in: V^T of the same 200 rows
+    with `offset` other rows in front is bit-equal to the rows alone (q and k carry the rotary position, which moves
+    with the offset).  Found with the padded == packed test in fold mode: the compiler had fused the rstd * acc + bias
+    of V elements 0 and 3 of each 4-token group with the fp16 conversion (one rounding) and left elements 1 and 2 with
+    two, so V changed by an ulp with the row index modulo 4."""
+    n, E, H = 200, 1280, 20
+    g = _gen(3)
+    x = torch.randn(n, E, device="cuda", generator=g) * 2 + 0.1
+    gamma = 1 + 0.1 * torch.randn(E, device="cuda", generator=g)
+    beta = 0.1 * torch.randn(E, device="cuda", generator=g)
+    w = torch.randn(3 * E, E, device="cuda", generator=g) / math.sqrt(E)
+    bias = 0.1 * torch.randn(3 * E, device="cuda", generator=g)
+    wf, b2 = fold_weight(w, gamma, beta)
+    qkv = ops.QkvHandle(E, H)
+
+    def run(k):
+        T = n + k
+        xx = torch.cat([torch.randn(k, E, device="cuda", generator=g), x]) if k else x
+        y, _, rstd = rowstats(xx)
+        rstd_p = torch.zeros((T + 255) // 256 * 256, device="cuda")
+        rstd_p[:T] = rstd
+        q = torch.empty((1, H, T, 64), dtype=torch.float16, device="cuda")
+        kk = torch.empty_like(q)
+        vt = torch.zeros((1, H, 64, (T + 63) // 64 * 64), dtype=torch.float16, device="cuda")
+        N.check(N.lib.esmk_op_qkv_rope_ln(qkv.h, N.ptr(y), N.ptr(wf), N.ptr(bias), N.ptr(b2), N.ptr(rstd_p), N.ptr(q), N.ptr(kk),
+                                          N.ptr(vt), 1, T, 1, N.cur_stream()))
+        t = torch.arange(T, device="cuda")
+        t16 = t & 15  # the key permutation of V^T (include/esmk.h: 4-groups 1 and 2 of each 16 keys swapped)
+        tp = (t & ~15) | (((t16 >> 2) & 1) << 3) | (((t16 >> 3) & 1) << 2) | (t16 & 3)
+        return vt[0][:, :, tp][:, :, k:].clone()
+
+    v0, vk = run(0), run(offset)
+    assert torch.equal(v0, vk), int((v0 != vk).sum())
+
+
 def build(L, E, H, seed):
     sd = synth_esm2_state_dict(L, E, H, seed=seed)
     with skip_param_init():
