@@ -367,6 +367,7 @@ void gemm_set_impl(int impl, int var) {
 // Start-up delay of one workgroup group in the residual GEMMs (gemm9.hip), as a fraction of a tile's main loop
 // (nk K tiles x ~2700 cycles); < 0 = not read yet (ESMK_RESID_DESYNC / ESMK_RESID_DESYNC_GROUP, esmk_debug_set).
 static int g_lnf_dbg = 0;
+static int g_qkv_one = -2;  // -2: not set (environment decides)
 static double g_desync = -1.0;
 static int g_desync_group = -1;
 constexpr double kDesyncDefault = 0.0;
@@ -374,6 +375,7 @@ bool gemm_set_knob(const char* key, double value) {
     if (strcmp(key, "resid_desync") == 0) g_desync = value < 0 ? 0.0 : value;
     else if (strcmp(key, "resid_desync_group") == 0) g_desync_group = (int)value;
     else if (strcmp(key, "lnf_dbg") == 0) g_lnf_dbg = (int)value;
+    else if (strcmp(key, "qkv_one_launch") == 0) g_qkv_one = (int)value < -1 ? -2 : (int)value;
     else return false;
     return true;
 }
@@ -393,8 +395,8 @@ static void desync_for(GemmArgs& q, long long tiles) {
     }
 }
 
-hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st) {
-    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipErrorInvalidValue;
+// ESMK_GEMM_IMPL / ESMK_GEMM9_* are read from the environment ONCE (launches may come from several host threads)
+static void gemm_env_init() {
     static std::once_flag env_once;
     std::call_once(env_once, [] {
         if (g_impl < 0) {  // not set through esmk_debug_gemm_impl
@@ -406,6 +408,41 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
         if (const char* k = getenv("ESMK_GEMM9_MIN_K")) g_mink9 = atoi(k);
         if (const char* v = getenv("ESMK_GEMM9_VAR")) g_auto_var = atoi(v);  // issue pattern of the auto choice (2 | 3: A/B)
     });
+}
+
+// Cost of a dense gemm9 launch in the unit the tile-height choice below uses: rounds of tiles over the 256 workgroups, a
+// half-height tile counted as 0.58 of a full one (profiles/r3_gemm9_half_height_b4.log).
+static double gemm9_round_cost(int M, int N) {
+    const long long tn = (N + 255) / 256;
+    const long long tiles = (long long)((M + 255) / 256) * tn, tiles_h = (long long)((M + 127) / 128) * tn;
+    const double cost_f = (double)((tiles + 255) / 256), cost_h = 0.58 * (double)((tiles_h + 255) / 256);
+    return cost_h < 0.92 * cost_f ? cost_h : cost_f;
+}
+
+// q / k (N = 2E) and v (N = E) as ONE launch (EPI_QKV_ALL)?  Only when it saves rounds: the two launches each round their
+// tile count up to whole rounds of 256 workgroups, the combined launch rounds once (B = 1 x 1022 at E = 1280: 80 + 40
+// half-height tiles = two part-filled rounds against one of 120; B = 64: 10 + 5 against 15 rounds — no gain, the two launches stay).  ESMK_QKV_ONE_LAUNCH
+// = 0 / 1 forces the choice (A/B runs); the results are bit-identical either way.
+bool gemm_qkv_one_launch(const GemmArgs& qk) {
+    static const int env = [] { const char* e = getenv("ESMK_QKV_ONE_LAUNCH"); return e ? atoi(e) : -1; }();
+    static const bool env_old = [] { const char* e = getenv("ESMK_GEMM"); return e != nullptr && strcmp(e, "old") == 0; }();
+    gemm_env_init();
+    const int mode = g_qkv_one >= -1 ? g_qkv_one : env;  // esmk_debug_set("qkv_one_launch", -1 | 0 | 1) overrides the environment
+    GemmArgs all = qk;
+    all.N = 3 * qk.E;
+    if (mode == 0 || qk.N != 2 * qk.E || g_impl == 8 || env_old || qk.force_old || qk.force_generic || qk.dbg ||
+        !gemm9_supports(all, EPI_QKV_ALL))
+        return false;
+    if (mode == 1) return true;
+    // the combined kernel exists with half-height tiles only (the full-height instantiation holding both K loops ran out of
+    // registers: accumulator quads shuffled through VGPRs in the loop, 1.7 x the time per tile)
+    const long long tiles_h = (long long)((qk.M + 127) / 128) * ((3 * qk.E + 255) / 256);
+    return 0.58 * (double)((tiles_h + 255) / 256) < gemm9_round_cost(qk.M, 2 * qk.E) + gemm9_round_cost(qk.M, qk.E) - 0.25;
+}
+
+hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return hipErrorInvalidValue;
+    gemm_env_init();
     static const bool env_old = [] {
         const char* e = getenv("ESMK_GEMM");
         return e != nullptr && strcmp(e, "old") == 0;
@@ -413,9 +450,12 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
     // the LayerNorm-fold forms of the epilogues exist in gemm9 only: such a call never takes another kernel
     const bool lnf = gemm9_ln_fold(p, epi);
     if (lnf && !gemm9_supports(p, epi)) return hipErrorInvalidValue;
-    if (lnf || (!env_old && !p.force_old && !p.force_generic && !p.dbg && g_impl != 8 && gemm9_supports(p, epi))) {
+    // the one-launch q / k / v form exists in gemm9 only as well (the caller asks gemm_qkv_one_launch first)
+    if (epi == EPI_QKV_ALL && (!gemm9_supports(p, epi) || p.force_old || p.force_generic || p.dbg)) return hipErrorInvalidValue;
+    const bool only9 = lnf || epi == EPI_QKV_ALL;
+    if (only9 || (!env_old && !p.force_old && !p.force_generic && !p.dbg && g_impl != 8 && gemm9_supports(p, epi))) {
         static const bool hm9 = [] { const char* e = getenv("ESMK_GEMM9_HM"); return e == nullptr || atoi(e) != 0; }();
-        if (!lnf && g_impl == 9 && g_impl_var >= 0) {
+        if (!only9 && g_impl == 9 && g_impl_var >= 0) {
             GemmArgs q = p;
             if (epi == EPI_RESID_F32 && g_impl_var == 0 && p.half_m <= 0)
                 desync_for(q, (long long)((p.M + 255) / 256) * ((p.N + 255) / 256));
@@ -427,16 +467,16 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
         static const int policy = [] { const char* e = getenv("ESMK_GEMM9_POLICY"); return e ? atoi(e) : 1; }();
         const long long tn = (p.N + 255) / 256;
         const long long tiles = (long long)((p.M + 255) / 256) * tn, tiles_h = (long long)((p.M + 127) / 128) * tn;
-        if (lnf || (((g_mask9 >> epi) & 1) && (epi != EPI_RESID_F32 || p.K >= g_mink9))) {
+        if (only9 || (((g_mask9 >> epi) & 1) && (epi != EPI_RESID_F32 || p.K >= g_mink9))) {
             bool half, use9;
-            if (policy == 0 && !lnf) {
+            if (policy == 0 && !only9) {
                 half = p.half_m > 0 || (p.half_m == 0 && tiles < 256 && gemm8_half_height(p));
                 use9 = half ? hm9 : tiles >= 256;
             } else {
                 const double wg = 256.0;
                 const double cost_f = (double)((tiles + 255) / 256), cost_h = 0.58 * (double)((tiles_h + 255) / 256);
                 (void)wg;
-                half = p.half_m > 0 || (p.half_m == 0 && cost_h < 0.92 * cost_f);
+                half = p.half_m > 0 || (p.half_m == 0 && cost_h < 0.92 * cost_f) || epi == EPI_QKV_ALL;
                 use9 = true;
             }
             if (use9) {
@@ -444,7 +484,7 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
                 q.half_m = half ? 1 : 0;
                 q.lnf_dbg = g_lnf_dbg;
                 if (epi == EPI_RESID_F32 && !half && g_auto_var == 0 && !lnf) desync_for(q, tiles);
-                return launch_gemm9(q, epi, operand_dtype, (half || lnf) ? 0 : g_auto_var, st);
+                return launch_gemm9(q, epi, operand_dtype, (half || only9) ? 0 : g_auto_var, st);
             }
         }
     }

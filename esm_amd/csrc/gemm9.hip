@@ -436,7 +436,11 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base, i
 template <typename T, int EPI, int VAR = 0, bool HM = false, bool LNF = false>
 __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long long* timing) {
     static_assert(!LNF || EPI == EPI_RESID_F32 || EPI == EPI_QKV_ROPE || EPI == EPI_V_T || EPI == EPI_GELU_T, "LayerNorm fold: epilogue");
+    static_assert(!(LNF && EPI == EPI_QKV_ALL), "the one-launch q / k / v form has no LayerNorm-fold variant");
     constexpr bool LNC = LNF && EPI != EPI_RESID_F32;  // consumer
+    // MFMA orientation of a tile: V^T tiles have a lane own 4 consecutive tokens of one channel.  EPI_QKV_ALL decides per tile
+    // (wave uniform) and instantiates the K loop once per orientation.
+    using VtDefault = std::integral_constant<bool, EPI == EPI_V_T>;
     constexpr int TM = HM ? 128 : 256;     // tile height
     constexpr int NMI = HM ? 4 : 8;        // 16-row blocks of a wave's block
     constexpr int NPC = NMI + 8;           // DMA pieces per wave and K tile
@@ -629,7 +633,9 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     auto load_bias = [&](int n_base) ESMK_INL {
         bool done = false;
         if constexpr (EPI != EPI_V_T && !LNC) {
-            if (p.bias != nullptr) {
+            bool want = p.bias != nullptr;
+            if constexpr (EPI == EPI_QKV_ALL) want = want && n_base < 2 * p.E;  // v tiles: the epilogue adds the bias
+            if (want) {
                 const int g4 = lane >> 4;
                 if (n_base + 128 <= p.N) {
 #pragma unroll
@@ -653,7 +659,7 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     };
     // the two MFMAs of slot m (16 x 16 x 32: 16 cycles each): K half m / (NS / 2), block pair 2 m', 2 m' + 1 of the
     // half's 8 NMI (column block nj = idx / NMI, row block mi = idx % NMI)
-    auto mma1 = [&](const V8 (&fa)[NMI], const V8 (&fw)[8], int m, bool first) ESMK_INL {
+    auto mma1 = [&](const V8 (&fa)[NMI], const V8 (&fw)[8], int m, bool first, auto vt) ESMK_INL {
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             const int idx = 2 * (m % (NS / 2)) + pp;
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
             if constexpr (NO_MFMA) {
                 asm volatile("" ::"v"(fa[mi]), "v"(fw[nj]));
                 if (use_b) c = bv[nj];
-            } else if constexpr (EPI == EPI_V_T) {  // lane owns 4 consecutive tokens of one channel
+            } else if constexpr (decltype(vt)::value) {  // lane owns 4 consecutive tokens of one channel
                 c = use_b ? Op<T>::mma16(fa[mi], fw[nj], bv[nj]) : Op<T>::mma16(fa[mi], fw[nj], c);
             } else {  // lane owns 4 consecutive channels of one token
                 c = use_b ? Op<T>::mma16(fw[nj], fa[mi], bv[nj]) : Op<T>::mma16(fw[nj], fa[mi], c);
@@ -672,7 +678,7 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     };
 
     int cur = 0;
-    auto ktile = [&](bool first) ESMK_INL {
+    auto ktile = [&](bool first, auto vt) ESMK_INL {
         const int nxt = (cur + 1 == NST) ? 0 : cur + 1;
         const char* sb = smem + cur * BUF;
         const char* sn = smem + nxt * BUF;
@@ -690,8 +696,8 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
                 else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(IN_FLIGHT) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (m < NS / 2) mma1(xa, xw, m, first);
-            else mma1(ya, yw, m, first);
+            if (m < NS / 2) mma1(xa, xw, m, first, vt);
+            else mma1(ya, yw, m, first, vt);
             if constexpr (HM) {
                 if (m < NRD / 2) {
                     rd1(ya, yw, sb, 1, 2 * m);
@@ -773,11 +779,26 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
         constexpr int WRM = TM / 2;  // rows of a wave's block
         const int m_base = tmi * TM + wr * WRM, n_base = tni * 256 + wc * 128;
         stamp(it, 0);
-        ktile(true);
-        // (a `.p2align 6` in front of this loop changed nothing, for the fast and the slow instantiations alike:
-        // profiles/r4_ln_fold_ablation.log)
+        // EPI_QKV_ALL: a tile of columns [2E,3E) is a v tile (tni is wave uniform, 2E a multiple of the tile width)
+        bool v_tile = false;
+        if constexpr (EPI == EPI_QKV_ALL) v_tile = tni * 256 >= 2 * p.E;
+        if constexpr (EPI == EPI_QKV_ALL) {
+            if (v_tile) {
+                ktile(true, std::true_type{});
 #pragma unroll 1
-        for (int kt = 1; kt < nk; ++kt) ktile(false);
+                for (int kt = 1; kt < nk; ++kt) ktile(false, std::true_type{});
+            } else {
+                ktile(true, std::false_type{});
+#pragma unroll 1
+                for (int kt = 1; kt < nk; ++kt) ktile(false, std::false_type{});
+            }
+        } else {
+            ktile(true, VtDefault{});
+            // (a `.p2align 6` in front of this loop changed nothing, for the fast and the slow instantiations alike:
+            // profiles/r4_ln_fold_ablation.log)
+#pragma unroll 1
+            for (int kt = 1; kt < nk; ++kt) ktile(false, VtDefault{});
+        }
         stamp(it, 1);
         // the next tile's bias (bv is dead by now): on its way while this tile's epilogue runs where the epilogue
         // leaves 64 registers free, right behind the epilogue otherwise
@@ -812,6 +833,21 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
                 char* sl2 = slice + (HM ? 0 : hf * 4096);
                 if (f2) epilogue8m<T, EPI, true, false, false, NMI / 2, 8, NTS, NMI, LNF>(p, acc, 4 * hf, m_base, nb, lane, sl2, 0, 0, 0);
                 else epilogue8m<T, EPI, false, false, false, NMI / 2, 8, NTS, NMI, LNF>(p, acc, 4 * hf, m_base, nb, lane, sl2, 0, 0, 0);
+            }
+        } else if constexpr (EPI == EPI_QKV_ALL) {
+            if (v_tile) {  // the v launch's epilogue: columns and bias counted from 2E
+                const int col0 = 2 * p.E;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int nb = n_base - col0 + 64 * hf;
+                    const bool f2 = (m_base + WRM <= p.M) && (nb + 64 <= p.N - col0) && (p.T % 32 == 0);
+                    char* sl2 = slice + (HM ? 0 : hf * 4096);
+                    if (f2) epilogue8m<T, EPI_V_T, true, false, false, NMI / 2, 8, NTS, NMI, false, true>(p, acc, 4 * hf, m_base, nb, lane, sl2, 0, 0, 0, col0);
+                    else epilogue8m<T, EPI_V_T, false, false, false, NMI / 2, 8, NTS, NMI, false, true>(p, acc, 4 * hf, m_base, nb, lane, sl2, 0, 0, 0, col0);
+                }
+            } else {
+                if (full) epilogue9_t<T, EPI_QKV_ROPE, true, NTS, NMI, HM ? 16 : 32, false>(p, acc, m_base, n_base, lane, slice);
+                else epilogue9_t<T, EPI_QKV_ROPE, false, NTS, NMI, HM ? 16 : 32, false>(p, acc, m_base, n_base, lane, slice);
             }
         } else {
             if (full) epilogue9_t<T, EPI, true, NTS, NMI, HM ? 16 : 32, LNF>(p, acc, m_base, n_base, lane, slice);
@@ -879,8 +915,12 @@ bool gemm9_supports(const GemmArgs& p, int epi) {
     if (gemm9_ln_fold(p, epi) && p.a_kt_repeat) return false;  // the fold has no split-weight form
     if (p.a_row_bytes && (p.a_row_bytes % 16 != 0)) return false;
     if ((epi == EPI_QKV_ROPE || epi == EPI_V_T) && p.N % 64 != 0) return false;
+    // whole tiles on either side of column 2E; plain weights; no LayerNorm-fold form
+    if (epi == EPI_QKV_ALL && !(p.E > 0 && p.E % 128 == 0 && p.N == 3 * p.E && !p.a_kt_repeat && !p.a_row_bytes && p.ln_rstd == nullptr &&
+                                p.bias != nullptr))
+        return false;
     if ((long long)256 * p.K * 2 > 0x7fffffffLL) return false;  // a panel must fit a buffer descriptor
-    return epi >= EPI_STORE_T && epi <= EPI_V_T;
+    return (epi >= EPI_STORE_T && epi <= EPI_V_T) || epi == EPI_QKV_ALL;
 }
 
 template <typename T>
@@ -941,6 +981,7 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
             case EPI_RESID_F32: return launch9<T, EPI_RESID_F32, 0, true>(p, st);
             case EPI_QKV_ROPE: return launch9<T, EPI_QKV_ROPE, 0, true>(p, st);
             case EPI_V_T: return launch9<T, EPI_V_T, 0, true>(p, st);
+            case EPI_QKV_ALL: return launch9<T, EPI_QKV_ALL, 0, true>(p, st);
         }
     }
     if (var == 0) {
@@ -952,6 +993,7 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
             case EPI_RESID_F32: return launch9<T, EPI_RESID_F32>(p, st);
             case EPI_QKV_ROPE: return launch9<T, EPI_QKV_ROPE>(p, st);
             case EPI_V_T: return launch9<T, EPI_V_T>(p, st);
+            // EPI_QKV_ALL: half-height tiles only (above) — the full-height instantiation with both K loops spilled
         }
     }
     if constexpr (std::is_same<T, _Float16>::value) {

@@ -72,14 +72,22 @@ ESMK_DEV typename Op<T>::v4 pack4_(float a, float b, float c, float d) {
 // launch and should not push the operand panels out of the XCD's L2).
 // LNF (gemm9, EPI_V_T only): LayerNorm-fold consumer — value = ln_rstd[token] * acc + (bias + bias2)[channel]
 // (kernels.h, GemmArgs::ln_rstd; the buffer is padded to whole 256-row tiles, so the 4-token loads never leave it).
-template <typename T, int EPI, bool FULL, bool NOSTORE = false, bool GEN = false, int NI = 4, int NJT = 4, bool NT = false, int NMI = 8, bool LNF = false>
+// COL0 (EPI_V_T inside gemm9's one-launch q / k / v form): the v block starts at column col0 of the launch's N and bias;
+// n_base is counted from there.  (A template switch, not a defaulted argument: the plain instantiations keep their code.)
+template <typename T, int EPI, bool FULL, bool NOSTORE = false, bool GEN = false, int NI = 4, int NJT = 4, bool NT = false, int NMI = 8, bool LNF = false,
+          bool COL0 = false>
 ESMK_DEV void epilogue8m(const GemmArgs& p, f32x4 (&acc)[NJT][NMI], int nj0, int m_base, int n_base, int lane,
-                         char* wl, size_t out_off, int zo, int zi) {
+                         char* wl, size_t out_off, int zo, int zi, int col0 = 0) {
     using V4 = typename Op<T>::v4;
     using V8 = typename Op<T>::v8;
     const int g4 = lane >> 4, l16 = lane & 15;
-    if constexpr (!FULL)
-        if (n_base >= p.N || m_base >= p.M) return;  // wave uniform
+    if constexpr (!FULL) {
+        if constexpr (COL0) {
+            if (n_base >= p.N - col0 || m_base >= p.M) return;
+        } else {
+            if (n_base >= p.N || m_base >= p.M) return;  // wave uniform
+        }
+    }
 
     if constexpr (EPI == EPI_V_T) {
         // vt[b][head][dv][Tp], keys permuted inside groups of 16 (4-groups 1 and 2 swapped)
@@ -90,7 +98,8 @@ ESMK_DEV void epilogue8m(const GemmArgs& p, f32x4 (&acc)[NJT][NMI], int nj0, int
         float bvn[4];
 #pragma unroll
         for (int nj = 0; nj < 4; ++nj) {
-            bvn[nj] = p.bias[n_base + 16 * nj + l16];
+            if constexpr (COL0) bvn[nj] = p.bias[col0 + n_base + 16 * nj + l16];
+            else bvn[nj] = p.bias[n_base + 16 * nj + l16];
             if constexpr (LNF)
                 if (p.bias2 != nullptr) bvn[nj] += p.bias2[n_base + 16 * nj + l16];
         }

@@ -15,7 +15,11 @@ enum {
     EPI_RESID_F32 = 4,  // out fp32              += acc + bias
     EPI_QKV_ROPE = 5,   // fused q,k projection: bias, q scale, RoPE, head-major store (head_dim 64)
     EPI_V_T = 6,        // v projection stored transposed [B,H,64,Tp] for the attention kernel
-    EPI_MSA_CTX = 7     // MSA row attention context: out[((zo*R + n/64)*C + m)*ldc + zi*64 + n%64] (operand dtype)
+    EPI_MSA_CTX = 7,    // MSA row attention context: out[((zo*R + n/64)*C + m)*ldc + zi*64 + n%64] (operand dtype)
+    // q, k and v in ONE launch (gemm9 only; N = 3E, W and bias = the packed [3E] q | k | v rows, E a multiple of 128): tiles
+    // of columns [0,2E) run exactly as EPI_QKV_ROPE, tiles of [2E,3E) exactly as EPI_V_T — the same instruction sequence per
+    // tile as the two launches, hence the same bits; what changes is how many ROUNDS of tiles the 256 CUs need (small batches)
+    EPI_QKV_ALL = 8
 };
 
 struct GemmArgs {
@@ -92,6 +96,7 @@ void gemm8_set_timing(unsigned long long* dev_buf);
 // gemm9.hip: the same contract on one wave per SIMD (128 x 128 wave blocks); dense operands only.  var selects the
 // DMA schedule (0: 8 + 8 pieces, 1: 6 + 5 + 5) or a timing experiment (gemm9.hip)
 bool gemm9_supports(const GemmArgs& p, int epi);
+bool gemm_qkv_one_launch(const GemmArgs& qk);  // q / k and v as one EPI_QKV_ALL launch: supported and fewer rounds of tiles?
 bool gemm9_ln_fold(const GemmArgs& p, int epi);  // the call asks for the LayerNorm-fold form of its epilogue
 hipError_t launch_gemm9(const GemmArgs& p, int epi, int operand_dtype, int var, hipStream_t st);
 void gemm9_set_timing(unsigned long long* dev_buf);

@@ -256,7 +256,10 @@ int esmk_debug_gemm_impl(int impl, int variant);
  * epilogues of the two halves of the chip out of lockstep (gemm9.hip; environment: ESMK_RESID_DESYNC);
  * "resid_desync_group": 0 = odd XCDs late, 1 = every other workgroup of each XCD, 2 = four phases.
  * "attn_stagger" (>= 0): start-up delay, in shader cycles per wave slot, of the co-resident workgroups of the attention
- * kernel (attention.hip; environment: ESMK_ATTN_STAGGER). */
+ * kernel (attention.hip; environment: ESMK_ATTN_STAGGER).
+ * "qkv_one_launch": 1 / 0 = always / never run the q, k and v projections of a layer as ONE GEMM launch, -1 = the library's
+ * choice (one launch where it needs fewer rounds of tiles over the CUs, i.e. small batches; gemm.hip; environment:
+ * ESMK_QKV_ONE_LAUNCH). */
 int esmk_debug_set(const char* key, double value);
 
 /* Fused q/k/v projection + scaling + rotary + head split (multihead_attention.py:256-284,
