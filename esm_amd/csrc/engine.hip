@@ -818,7 +818,7 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
             ESMK_TRY(hipEventRecord(m->ev_join, m->side_stream));
             if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;  // q, k: weight rows [0,2EA)
             ESMK_TRY(hipStreamWaitEvent(st, m->ev_join, 0));
-        } else if (!fold && wsf == 1 && gemm_qkv_one_launch(g)) {
+        } else if (wsf == 1 && gemm_qkv_one_launch(g)) {
             // small batches: q, k and v in one launch — same tiles, same bits, fewer rounds over the CUs (kernels.h, EPI_QKV_ALL)
             GemmArgs ga = g;
             ga.N = 3 * EA;
@@ -1237,7 +1237,7 @@ static int qkv_rope_impl(esmk_model* m, const void* a_dev, const void* wqkv_dev,
     g.Tp = Tp;
     // log2_domain: q also carries log2(e), the form esmk_op_attention / esmk_op_attention_probs take (esmk_forward's own)
     g.scaling = (log2_domain ? kLog2e : 1.0f) / sqrtf((float)m->D);
-    if (ln_rstd_dev == nullptr && gemm_qkv_one_launch(g)) {  // as esmk_forward: one launch where it saves rounds of tiles
+    if (gemm_qkv_one_launch(g)) {  // as esmk_forward: one launch where it saves rounds of tiles
         g.N = 3 * m->E;
         ESMK_TRY(launch_gemm(g, EPI_QKV_ALL, m->cfg.operand_dtype, st));
         return 0;

@@ -435,8 +435,8 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base, i
 // EPI_QKV_ROPE / EPI_V_T / EPI_GELU_T = consumer (accumulators start from 0, row scale + bias in the epilogue).
 template <typename T, int EPI, int VAR = 0, bool HM = false, bool LNF = false>
 __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long long* timing) {
-    static_assert(!LNF || EPI == EPI_RESID_F32 || EPI == EPI_QKV_ROPE || EPI == EPI_V_T || EPI == EPI_GELU_T, "LayerNorm fold: epilogue");
-    static_assert(!(LNF && EPI == EPI_QKV_ALL), "the one-launch q / k / v form has no LayerNorm-fold variant");
+    static_assert(!LNF || EPI == EPI_RESID_F32 || EPI == EPI_QKV_ROPE || EPI == EPI_V_T || EPI == EPI_GELU_T || EPI == EPI_QKV_ALL,
+                  "LayerNorm fold: epilogue");
     constexpr bool LNC = LNF && EPI != EPI_RESID_F32;  // consumer
     // MFMA orientation of a tile: V^T tiles have a lane own 4 consecutive tokens of one channel.  EPI_QKV_ALL decides per tile
     // (wave uniform) and instantiates the K loop once per orientation.
@@ -842,12 +842,12 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
                     const int nb = n_base - col0 + 64 * hf;
                     const bool f2 = (m_base + WRM <= p.M) && (nb + 64 <= p.N - col0) && (p.T % 32 == 0);
                     char* sl2 = slice + (HM ? 0 : hf * 4096);
-                    if (f2) epilogue8m<T, EPI_V_T, true, false, false, NMI / 2, 8, NTS, NMI, false, true>(p, acc, 4 * hf, m_base, nb, lane, sl2, 0, 0, 0, col0);
-                    else epilogue8m<T, EPI_V_T, false, false, false, NMI / 2, 8, NTS, NMI, false, true>(p, acc, 4 * hf, m_base, nb, lane, sl2, 0, 0, 0, col0);
+                    if (f2) epilogue8m<T, EPI_V_T, true, false, false, NMI / 2, 8, NTS, NMI, LNF, true>(p, acc, 4 * hf, m_base, nb, lane, sl2, 0, 0, 0, col0);
+                    else epilogue8m<T, EPI_V_T, false, false, false, NMI / 2, 8, NTS, NMI, LNF, true>(p, acc, 4 * hf, m_base, nb, lane, sl2, 0, 0, 0, col0);
                 }
             } else {
-                if (full) epilogue9_t<T, EPI_QKV_ROPE, true, NTS, NMI, HM ? 16 : 32, false>(p, acc, m_base, n_base, lane, slice);
-                else epilogue9_t<T, EPI_QKV_ROPE, false, NTS, NMI, HM ? 16 : 32, false>(p, acc, m_base, n_base, lane, slice);
+                if (full) epilogue9_t<T, EPI_QKV_ROPE, true, NTS, NMI, HM ? 16 : 32, LNF>(p, acc, m_base, n_base, lane, slice);
+                else epilogue9_t<T, EPI_QKV_ROPE, false, NTS, NMI, HM ? 16 : 32, LNF>(p, acc, m_base, n_base, lane, slice);
             }
         } else {
             if (full) epilogue9_t<T, EPI, true, NTS, NMI, HM ? 16 : 32, LNF>(p, acc, m_base, n_base, lane, slice);
@@ -902,7 +902,7 @@ static hipError_t launch9(GemmArgs p, hipStream_t st) {
 // LayerNorm fold requested for this call? (producer: EPI_RESID_F32 + ln_part; consumer: q/k, v, fc1 epilogues + ln_rstd)
 bool gemm9_ln_fold(const GemmArgs& p, int epi) {
     if (epi == EPI_RESID_F32) return p.ln_part != nullptr;
-    if (epi == EPI_QKV_ROPE || epi == EPI_V_T || epi == EPI_GELU_T) return p.ln_rstd != nullptr;
+    if (epi == EPI_QKV_ROPE || epi == EPI_V_T || epi == EPI_GELU_T || epi == EPI_QKV_ALL) return p.ln_rstd != nullptr;
     return false;
 }
 
@@ -915,9 +915,8 @@ bool gemm9_supports(const GemmArgs& p, int epi) {
     if (gemm9_ln_fold(p, epi) && p.a_kt_repeat) return false;  // the fold has no split-weight form
     if (p.a_row_bytes && (p.a_row_bytes % 16 != 0)) return false;
     if ((epi == EPI_QKV_ROPE || epi == EPI_V_T) && p.N % 64 != 0) return false;
-    // whole tiles on either side of column 2E; plain weights; no LayerNorm-fold form
-    if (epi == EPI_QKV_ALL && !(p.E > 0 && p.E % 128 == 0 && p.N == 3 * p.E && !p.a_kt_repeat && !p.a_row_bytes && p.ln_rstd == nullptr &&
-                                p.bias != nullptr))
+    // whole tiles on either side of column 2E; plain (not split) weights
+    if (epi == EPI_QKV_ALL && !(p.E > 0 && p.E % 128 == 0 && p.N == 3 * p.E && !p.a_kt_repeat && !p.a_row_bytes && p.bias != nullptr))
         return false;
     if ((long long)256 * p.K * 2 > 0x7fffffffLL) return false;  // a panel must fit a buffer descriptor
     return (epi >= EPI_STORE_T && epi <= EPI_V_T) || epi == EPI_QKV_ALL;
@@ -962,6 +961,7 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
                 case EPI_QKV_ROPE: return launch9<T, EPI_QKV_ROPE, 0, true, true>(p, st);
                 case EPI_V_T: return launch9<T, EPI_V_T, 0, true, true>(p, st);
                 case EPI_GELU_T: return launch9<T, EPI_GELU_T, 0, true, true>(p, st);
+                case EPI_QKV_ALL: return launch9<T, EPI_QKV_ALL, 0, true, true>(p, st);
             }
         }
         switch (epi) {

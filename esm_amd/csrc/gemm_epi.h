@@ -101,7 +101,7 @@ ESMK_DEV void epilogue8m(const GemmArgs& p, f32x4 (&acc)[NJT][NMI], int nj0, int
             if constexpr (COL0) bvn[nj] = p.bias[col0 + n_base + 16 * nj + l16];
             else bvn[nj] = p.bias[n_base + 16 * nj + l16];
             if constexpr (LNF)
-                if (p.bias2 != nullptr) bvn[nj] += p.bias2[n_base + 16 * nj + l16];
+                if (p.bias2 != nullptr) bvn[nj] += p.bias2[(COL0 ? col0 : 0) + n_base + 16 * nj + l16];
         }
         const bool aligned = FULL || (p.T % 32 == 0);  // a 32-token piece = one aligned run of one sequence
         const bool perm = !GEN || (p.vt_rows == 0);  // ESM-2 attention consumes permuted keys, the MSA context GEMM plain ones

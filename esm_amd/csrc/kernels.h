@@ -16,7 +16,7 @@ enum {
     EPI_QKV_ROPE = 5,   // fused q,k projection: bias, q scale, RoPE, head-major store (head_dim 64)
     EPI_V_T = 6,        // v projection stored transposed [B,H,64,Tp] for the attention kernel
     EPI_MSA_CTX = 7,    // MSA row attention context: out[((zo*R + n/64)*C + m)*ldc + zi*64 + n%64] (operand dtype)
-    // q, k and v in ONE launch (gemm9 only; N = 3E, W and bias = the packed [3E] q | k | v rows, E a multiple of 128): tiles
+    // q, k and v in ONE launch (gemm9 only, half-height tiles, plain or LayerNorm-fold consumer form; N = 3E, W and bias = the packed [3E] q | k | v rows, E a multiple of 128): tiles
     // of columns [0,2E) run exactly as EPI_QKV_ROPE, tiles of [2E,3E) exactly as EPI_V_T — the same instruction sequence per
     // tile as the two launches, hence the same bits; what changes is how many ROUNDS of tiles the 256 CUs need (small batches)
     EPI_QKV_ALL = 8

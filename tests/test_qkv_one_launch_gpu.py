@@ -4,6 +4,7 @@ sequence lengths, both tile heights, padded and token-packed batches.  Reference
 split of esm/multihead_attention.py:256-284,354-355."""
 import ctypes
 import math
+import os
 
 import pytest
 import torch
@@ -63,10 +64,47 @@ def test_one_launch_is_taken_and_is_refused_where_it_does_not_apply():
     assert N.lib.esmk_debug_set(b"no_such_knob", ctypes.c_double(1)) != 0
 
 
+@pytest.mark.parametrize("B,T", [(4, 1022), (1, 1022), (2, 763), (8, 256)])
+def test_layernorm_fold_form_one_launch_equals_two_launches(B, T):
+    """The LayerNorm-fold consumer form (esmk_op_qkv_rope_ln: row scale + folded bias in the epilogues) through the one
+    launch and through the two."""
+    E, H = 1280, 20
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + T + 1)
+    M = B * T
+    x = torch.randn(M, E, device="cuda", generator=g) * 2 + 0.3
+    gamma = 1 + 0.1 * torch.randn(E, device="cuda", generator=g)
+    beta = 0.1 * torch.randn(E, device="cuda", generator=g)
+    w = torch.randn(3 * E, E, device="cuda", generator=g) / math.sqrt(E)
+    bias = 0.1 * torch.randn(3 * E, device="cuda", generator=g)
+    wf = torch.zeros(3 * E, E, dtype=torch.float16, device="cuda")
+    b2 = torch.empty(3 * E, device="cuda")
+    N.check(N.lib.esmk_op_fold_weight(N.ptr(w), 0, N.ptr(gamma), N.ptr(beta), N.ptr(wf), 1, N.ptr(b2), 3 * E, E, E, N.cur_stream()))
+    Mp = (M + 255) // 256 * 256
+    y = torch.zeros(M, E, dtype=torch.float16, device="cuda")
+    mean, rstd = torch.zeros(Mp, device="cuda"), torch.zeros(Mp, device="cuda")
+    N.check(N.lib.esmk_op_rowstats(N.ptr(x), N.ptr(y), N.ptr(mean), N.ptr(rstd), M, E, E, 1, N.cur_stream()))
+    qkv = ops.QkvHandle(E, H)
+    Tp = (T + 63) // 64 * 64
+    outs = []
+    for mode in (0, 1):
+        knob(mode)
+        q = torch.empty((B, H, T, 64), dtype=torch.float16, device="cuda")
+        k = torch.empty_like(q)
+        vt = torch.zeros((B, H, 64, Tp), dtype=torch.float16, device="cuda")
+        N.check(N.lib.esmk_op_qkv_rope_ln(qkv.h, N.ptr(y), N.ptr(wf), N.ptr(bias), N.ptr(b2), N.ptr(rstd), N.ptr(q), N.ptr(k),
+                                          N.ptr(vt), B, T, 1, N.cur_stream()))
+        outs.append((q, k, vt[..., :T].clone()))
+    for name, a, b in zip("q k vt".split(), outs[0], outs[1]):
+        assert torch.isfinite(b.float()).all(), name
+        assert torch.equal(a, b), (name, int((a != b).sum()))
+
+
+@pytest.mark.parametrize("fold", [False, True], ids=["plain", "ln_fold"])
 @pytest.mark.parametrize("lens", [[1022, 1022, 1022, 1022], [150, 33, 97, 128, 64], [763, 336]])
-def test_forward_bits_do_not_depend_on_the_launch_form(lens):
+def test_forward_bits_do_not_depend_on_the_launch_form(lens, fold, monkeypatch):
     """Whole forward (650M dims, 3 layers): logits, representations and contacts with the combined launch forced on ==
-    forced off == the library's choice, padded and token-packed."""
+    forced off == the library's choice, padded and token-packed, plain and LayerNorm-fold engines."""
+    monkeypatch.setenv("ESM_AMD_LN_FOLD", "1" if fold else "0")
     L, E, H = 3, 1280, 20
     sd = synth_esm2_state_dict(L, E, H, seed=11)
     with skip_param_init():
