@@ -29,12 +29,13 @@ def _restore_knob():
 
 @pytest.mark.parametrize("B,T,E,H", [(4, 1022, 1280, 20), (1, 1022, 1280, 20), (3, 160, 1280, 20), (2, 763, 1280, 20),
                                      (8, 256, 1280, 20), (16, 1022, 1280, 20), (5, 333, 640, 10), (2, 64, 2560, 40)])
-def test_one_launch_equals_two_launches_bit_for_bit(B, T, E, H):
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_one_launch_equals_two_launches_bit_for_bit(B, T, E, H, dtype):
     g = torch.Generator(device="cuda").manual_seed(B * 1000 + T)
-    a = (torch.randn(B * T, E, device="cuda", generator=g)).half()
-    w = (torch.randn(3 * E, E, device="cuda", generator=g) / math.sqrt(E)).half()
+    a = (torch.randn(B * T, E, device="cuda", generator=g)).to(dtype)
+    w = (torch.randn(3 * E, E, device="cuda", generator=g) / math.sqrt(E)).to(dtype)
     bias = 0.1 * torch.randn(3 * E, device="cuda", generator=g)
-    qkv = ops.QkvHandle(E, H)
+    qkv = ops.QkvHandle(E, H, operand_dtype=dtype)
     Tp = (T + 63) // 64 * 64
     outs = []
     for mode in (0, 1):
