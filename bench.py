@@ -52,6 +52,11 @@ PMC_SUMMARY = {"esm2_650m": os.path.join(ROOT, "profiles", "r4_pmc_summary.json"
                "esm2_3b_contacts": os.path.join(ROOT, "profiles", "r4_pmc_summary_esm2_3b_contacts.json")}
 
 
+# Libraries whose device code differs from a profiled one ONLY in kernels the bench workloads do not launch, with the
+# function-by-function ISA comparison that shows it (tools/isa_report.py): {profiled hash: {this hash: {evidence, differs_in}}}
+ISA_EQUIVALENCE = os.path.join(ROOT, "profiles", "r4_isa_equivalence.json")
+
+
 def argmax_report(logits, ref_logits):
     """Token-argmax agreement with the CPU path.  Random-init weights give near-tied logits, so the raw agreement
     counts coin flips; `decided` restricts it to positions whose top-2 margin in the reference exceeds twice the
@@ -167,16 +172,28 @@ def pmc_traffic(kernel_class, src_hash, workload="esm2_650m"):
     """HBM bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes of that workload (tools/
     profile_bench.sh -> profiles/r4_pmc_summary*.json; FETCH_SIZE doubled as the microarch guide prescribes for
     gfx950).  The summary records the source hash of the library it profiled: a different build -> null (never a
-    stale number)."""
+    stale number), unless profiles/r4_isa_equivalence.json names it as identical, kernel by kernel, in everything the bench
+    workloads launch (then the source string carries both hashes and the evidence file)."""
     try:
         with open(PMC_SUMMARY[workload]) as f:
             s = json.load(f)
+        also = ""
         if s.get("library_src_hash") != src_hash:
-            return None, f"PMC summary is from build {s.get('library_src_hash')}, this is {src_hash}"
-        # where the number comes from: the committed summary file + the hash of the library it profiled (= this library)
+            # a different build: accepted only if the committed ISA comparison lists it as identical in every kernel these
+            # workloads launch — and the source string says so; anything else -> null (never a stale number)
+            try:
+                with open(ISA_EQUIVALENCE) as f:
+                    eq = json.load(f).get(s.get("library_src_hash"), {}).get(src_hash)
+            except OSError:
+                eq = None
+            if not eq:
+                return None, f"PMC summary is from build {s.get('library_src_hash')}, this is {src_hash}"
+            also = (f"; this library {src_hash} differs from it only in {eq['differs_in']}, which no bench workload's reported "
+                    f"kernel class launches: {eq['evidence']}")
+        # where the number comes from: the committed summary file + the hash of the library it profiled
         return (s["kernels"][kernel_class]["hbm_bytes_corrected"],
                 f"{os.path.relpath(PMC_SUMMARY[workload], os.path.dirname(os.path.abspath(__file__)))} (rocprofv3 PMC passes of library "
-                f"{s.get('library_src_hash')}" + (f", commit {s['git_sha']}" if s.get("git_sha") else "") + ")")
+                f"{s.get('library_src_hash')}" + (f", commit {s['git_sha']}" if s.get("git_sha") else "") + also + ")")
     except Exception as e:  # missing file / class
         return None, str(e)
 

@@ -727,6 +727,19 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // LayerNorm-fold producer, full-height tiles: pin every accumulator quad to the AGPR file across the loop edge.  Left
+        // alone, the allocator of this instantiation (512 registers in use) carried ONE quad through the edge in VGPRs:
+        // 4 v_accvgpr_write at the top of every K tile and, after the quad's last MFMA, s_nop + 4 v_accvgpr_read — a wait for
+        // the matrix pipe in the middle of the issue stream, every K tile.  That, not the epilogue, was the "main loop that
+        // runs 20 % slower with the same instructions" of DESIGN.md 4.8: with the pin the loop is the plain kernel's 268
+        // instructions (tools/isa_report.py) and fc2 / out-proj as producers cost + 1.7 / + 1.6 ms per step instead of
+        // + 6.1 / + 2.9 (B = 64) — the fold now wins at every batch size (profiles/r4_ln_fold_acc_pin.log).
+        if constexpr (LNF && EPI == EPI_RESID_F32 && !HM) {
+#pragma unroll
+            for (int nj = 0; nj < 8; ++nj)
+#pragma unroll
+                for (int mi = 0; mi < NMI; ++mi) asm volatile("" : "+a"(acc[nj][mi]));
+        }
         cur = nxt;
     };
 

@@ -188,3 +188,32 @@ def test_skip_param_init_then_strict_load_gives_the_state_dict():
     assert torch.nn.Linear.reset_parameters is before
     lin = torch.nn.Linear(8, 8)
     assert lin.weight.abs().sum() > 0  # constructors fill again outside the context
+
+
+def test_pmc_traffic_is_gated_by_the_library_hash(tmp_path, monkeypatch):
+    """roofline.traffic comes from the committed PMC summary only for the library it profiled — or for one the committed
+    ISA comparison names as identical in every kernel the workloads launch, and then the source string says so."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    summ = tmp_path / "pmc.json"
+    summ.write_text(json.dumps({"library_src_hash": "aaaa", "git_sha": None,
+                                "kernels": {"gemm_fc1_gelu": {"hbm_bytes_corrected": 123.0}}}))
+    eq = tmp_path / "eq.json"
+    eq.write_text(json.dumps({"aaaa": {"bbbb": {"evidence": "profiles/x.txt", "differs_in": "kernel K"}}}))
+    monkeypatch.setitem(bench.PMC_SUMMARY, "esm2_650m", str(summ))
+    monkeypatch.setattr(bench, "ISA_EQUIVALENCE", str(eq))
+    v, src = bench.pmc_traffic("gemm_fc1_gelu", "aaaa")
+    assert v == 123.0 and "aaaa" in src and "differs" not in src
+    v, src = bench.pmc_traffic("gemm_fc1_gelu", "bbbb")
+    assert v == 123.0 and "aaaa" in src and "bbbb" in src and "kernel K" in src and "profiles/x.txt" in src
+    v, src = bench.pmc_traffic("gemm_fc1_gelu", "cccc")
+    assert v is None and "aaaa" in src and "cccc" in src
+    monkeypatch.setattr(bench, "ISA_EQUIVALENCE", str(tmp_path / "missing.json"))
+    assert bench.pmc_traffic("gemm_fc1_gelu", "bbbb")[0] is None
+    # the committed files: the equivalence table only names hashes whose evidence file exists
+    with open(os.path.join(ROOT, "profiles", "r4_isa_equivalence.json")) as f:
+        for profiled, others in json.load(f).items():
+            for h, e in others.items():
+                assert os.path.exists(os.path.join(ROOT, e["evidence"])), e
+                assert h in open(os.path.join(ROOT, e["evidence"])).read() and profiled in open(os.path.join(ROOT, e["evidence"])).read()
