@@ -99,7 +99,9 @@ def test_consumer_gelu_against_torch(M, Nn, K, half_m):
     assert err < 1e-3
 
 
-@pytest.mark.parametrize("M,Nn,K,half_m", [(1024, 1280, 1280, 0), (2048, 1280, 5120, 0), (1000, 480, 320, 0), (777, 264, 192, 0), (512, 1280, 1280, 1)])
+# half_m: 0 = the library's choice (half-height tiles at these sizes), 1 / -1 = force half- / full-height tiles (the two kernels)
+@pytest.mark.parametrize("M,Nn,K,half_m", [(1024, 1280, 1280, 0), (2048, 1280, 5120, 0), (1000, 480, 320, 0), (777, 264, 192, 0), (512, 1280, 1280, 1),
+                                           (1024, 1280, 1280, -1), (2048, 1280, 5120, -1), (1000, 480, 320, -1)])
 def test_producer_against_plain_residual_gemm(M, Nn, K, half_m):
     """out must be bit-identical to the plain residual epilogue; h16 = fp16(out - mean_prev); partial sums vs torch."""
     g = _gen(4)
