@@ -36,6 +36,11 @@ struct Op<_Float16> {
     // 16 x 16 x 32: D[i][j] += sum_k a[i][k] b[j][k];  lane l supplies a[l & 15][8 (l >> 4) .. + 8], b likewise, and
     // holds D[4 (l >> 4) + r][l & 15], r = 0..3
     static ESMK_DEV f32x4 mma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    // The same product accumulated IN PLACE, D tied to C in the AGPR file.  For the peeled first K tile of gemm9: left to the
+    // builtin, the allocator gives the second K half's results registers of their own (D != C), runs out of AGPRs and parks
+    // 24 - 40 accumulator quads in VGPRs (s_nop 7 + 4 v_accvgpr_read behind their MFMA, 4 v_accvgpr_write later).  The
+    // compiler does not see an MFMA in here: the caller keeps readers of c (LDS writes, accvgpr reads) >= 12 wait states away.
+    static ESMK_DEV void mma16_tied(v8 a, v8 b, f32x4& c) { asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
     static ESMK_DEV _Float16 from(float x) { return (_Float16)x; }
     static ESMK_DEV float to(_Float16 x) { return (float)x; }
 };
@@ -53,6 +58,7 @@ struct Op<__bf16> {
         return d;
     }
     static ESMK_DEV f32x4 mma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static ESMK_DEV void mma16_tied(v8 a, v8 b, f32x4& c) { asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
     static ESMK_DEV __bf16 from(float x) { return (__bf16)x; }
     static ESMK_DEV float to(__bf16 x) { return (float)x; }
 };

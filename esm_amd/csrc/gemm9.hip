@@ -473,6 +473,11 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     constexpr int M_B2 = HM ? 16 : 52;
     constexpr bool STAGGER = (VAR & 4) != 0;
     constexpr bool NO_BAR = (VAR & 8) != 0;
+    // first K tile of a full-height tile: its second K half accumulates through the tied inline-asm MFMA (common.h)
+#ifndef ESMK_G9_TIE1
+#define ESMK_G9_TIE1 1
+#endif
+    constexpr bool TIE1 = ESMK_G9_TIE1 && !HM && !NO_MFMA;
     // VAR & 256 / 512 (timing experiments): the K loop of a tile starts at a K offset that depends on the workgroup
     // (256) or on the tile's column block (512) and wraps — the vendor kernel's "StaggerU" against all CUs sweeping the
     // same K offset of their operand rows at once.  256 changes the summation order with the tile -> workgroup map.
@@ -659,16 +664,29 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     };
     // the two MFMAs of slot m (16 x 16 x 32: 16 cycles each): K half m / (NS / 2), block pair 2 m', 2 m' + 1 of the
     // half's 8 NMI (column block nj = idx / NMI, row block mi = idx % NMI)
-    auto mma1 = [&](const V8 (&fa)[NMI], const V8 (&fw)[8], int m, bool first, auto vt) ESMK_INL {
+    auto mma1 = [&](const V8 (&fa)[NMI], const V8 (&fw)[8], int m, auto first_t, auto vt, auto half_t) ESMK_INL {
+        constexpr bool first = decltype(first_t)::value;
+        constexpr bool second_half = decltype(half_t)::value;
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             const int idx = 2 * (m % (NS / 2)) + pp;
             const int nj = idx / NMI, mi = idx % NMI;
             f32x4& c = acc[nj][mi];
             const bool use_b = first && m < NS / 2;  // the tile's first K half: C operand = bias
+            // the first K tile's second half, full-height tiles: accumulate in place (Op<T>::mma16_tied)
+            constexpr bool tied = TIE1 && first && second_half;
             if constexpr (NO_MFMA) {
                 asm volatile("" ::"v"(fa[mi]), "v"(fw[nj]));
                 if (use_b) c = bv[nj];
+            } else if constexpr (TIE1 && first) {
+                if constexpr (tied) {
+                    if constexpr (decltype(vt)::value) Op<T>::mma16_tied(fa[mi], fw[nj], c);
+                    else Op<T>::mma16_tied(fw[nj], fa[mi], c);
+                } else if constexpr (decltype(vt)::value) {
+                    c = Op<T>::mma16(fa[mi], fw[nj], bv[nj]);
+                } else {
+                    c = Op<T>::mma16(fw[nj], fa[mi], bv[nj]);
+                }
             } else if constexpr (decltype(vt)::value) {  // lane owns 4 consecutive tokens of one channel
                 c = use_b ? Op<T>::mma16(fa[mi], fw[nj], bv[nj]) : Op<T>::mma16(fa[mi], fw[nj], c);
             } else {  // lane owns 4 consecutive channels of one token
@@ -678,7 +696,7 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
     };
 
     int cur = 0;
-    auto ktile = [&](bool first, auto vt) ESMK_INL {
+    auto ktile = [&](auto first, auto vt) ESMK_INL {
         const int nxt = (cur + 1 == NST) ? 0 : cur + 1;
         const char* sb = smem + cur * BUF;
         const char* sn = smem + nxt * BUF;
@@ -696,8 +714,8 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
                 else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(IN_FLIGHT) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (m < NS / 2) mma1(xa, xw, m, first, vt);
-            else mma1(ya, yw, m, first, vt);
+            if (m < NS / 2) mma1(xa, xw, m, first, vt, std::false_type{});
+            else mma1(ya, yw, m, first, vt, std::true_type{});
             if constexpr (HM) {
                 if (m < NRD / 2) {
                     rd1(ya, yw, sb, 1, 2 * m);
@@ -734,12 +752,15 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
         // runs 20 % slower with the same instructions" of DESIGN.md 4.8: with the pin the loop is the plain kernel's 268
         // instructions (tools/isa_report.py) and fc2 / out-proj as producers cost + 1.7 / + 1.6 ms per step instead of
         // + 6.1 / + 2.9 (B = 64) — the fold now wins at every batch size (profiles/r4_ln_fold_acc_pin.log).
-        if constexpr (LNF && EPI == EPI_RESID_F32 && !HM) {
+        if constexpr (((LNF && EPI == EPI_RESID_F32) || EPI == EPI_QKV_ALL) && !HM) {
 #pragma unroll
             for (int nj = 0; nj < 8; ++nj)
 #pragma unroll
                 for (int mi = 0; mi < NMI; ++mi) asm volatile("" : "+a"(acc[nj][mi]));
         }
+        // K = 64 (one K tile): the epilogue's reads of the accumulators follow the tied MFMAs, which the compiler's hazard
+        // recogniser does not see — 16 wait states cover a 4-pass MFMA
+        if constexpr (TIE1 && decltype(first)::value) asm volatile("s_nop 7\n\ts_nop 7");
         cur = nxt;
     };
 
@@ -797,20 +818,20 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
         if constexpr (EPI == EPI_QKV_ALL) v_tile = tni * 256 >= 2 * p.E;
         if constexpr (EPI == EPI_QKV_ALL) {
             if (v_tile) {
-                ktile(true, std::true_type{});
+                ktile(std::true_type{}, std::true_type{});
 #pragma unroll 1
-                for (int kt = 1; kt < nk; ++kt) ktile(false, std::true_type{});
+                for (int kt = 1; kt < nk; ++kt) ktile(std::false_type{}, std::true_type{});
             } else {
-                ktile(true, std::false_type{});
+                ktile(std::true_type{}, std::false_type{});
 #pragma unroll 1
-                for (int kt = 1; kt < nk; ++kt) ktile(false, std::false_type{});
+                for (int kt = 1; kt < nk; ++kt) ktile(std::false_type{}, std::false_type{});
             }
         } else {
-            ktile(true, VtDefault{});
+            ktile(std::true_type{}, VtDefault{});
             // (a `.p2align 6` in front of this loop changed nothing, for the fast and the slow instantiations alike:
             // profiles/r4_ln_fold_ablation.log)
 #pragma unroll 1
-            for (int kt = 1; kt < nk; ++kt) ktile(false, VtDefault{});
+            for (int kt = 1; kt < nk; ++kt) ktile(std::false_type{}, VtDefault{});
         }
         stamp(it, 1);
         // the next tile's bias (bv is dead by now): on its way while this tile's epilogue runs where the epilogue
@@ -982,6 +1003,7 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
             case EPI_QKV_ROPE: return launch9<T, EPI_QKV_ROPE, 0, false, true>(p, st);
             case EPI_V_T: return launch9<T, EPI_V_T, 0, false, true>(p, st);
             case EPI_GELU_T: return launch9<T, EPI_GELU_T, 0, false, true>(p, st);
+            case EPI_QKV_ALL: return launch9<T, EPI_QKV_ALL, 0, false, true>(p, st);
         }
         return hipErrorInvalidValue;
     }
@@ -1006,7 +1028,7 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
             case EPI_RESID_F32: return launch9<T, EPI_RESID_F32>(p, st);
             case EPI_QKV_ROPE: return launch9<T, EPI_QKV_ROPE>(p, st);
             case EPI_V_T: return launch9<T, EPI_V_T>(p, st);
-            // EPI_QKV_ALL: half-height tiles only (above) — the full-height instantiation with both K loops spilled
+            case EPI_QKV_ALL: return launch9<T, EPI_QKV_ALL>(p, st);
         }
     }
     if constexpr (std::is_same<T, _Float16>::value) {
