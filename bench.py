@@ -47,14 +47,20 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0        # spec; 6.29 TB/s is the measured copy ceiling
 HBM_ACHIEVABLE_GBS = 6300.0
-PMC_SUMMARY = {"esm2_650m": os.path.join(ROOT, "profiles", "r4_pmc_summary.json"),
-               "msa1b": os.path.join(ROOT, "profiles", "r4_pmc_summary_msa1b.json"),
-               "esm2_3b_contacts": os.path.join(ROOT, "profiles", "r4_pmc_summary_esm2_3b_contacts.json")}
+DEFAULT_BATCH = {"esm2_650m": 64, "esm2_3b_contacts": 32, "msa1b": 1, "extract_650m": 64}
+PMC_DIR = os.path.join(ROOT, "profiles")
+PMC_ROUND = "r5"
 
 
-# Libraries whose device code differs from a profiled one ONLY in kernels the bench workloads do not launch, with the
-# function-by-function ISA comparison that shows it (tools/isa_report.py): {profiled hash: {this hash: {evidence, differs_in}}}
-ISA_EQUIVALENCE = os.path.join(ROOT, "profiles", "r4_isa_equivalence.json")
+def pmc_summary_path(workload, batch, ln_fold):
+    """profiles/r5_pmc_summary_<workload>[_b<B>][_plain].json: one file per (workload, per-GPU batch, LayerNorm-fold mode)
+    — the default batch and the default (fold) mode carry no suffix.  tools/profile_bench.sh writes them."""
+    tag = workload
+    if batch not in (None, 0, DEFAULT_BATCH.get(workload)):
+        tag += f"_b{batch}"
+    if ln_fold is False:
+        tag += "_plain"
+    return os.path.join(PMC_DIR, f"{PMC_ROUND}_pmc_summary_{tag}.json")
 
 
 def argmax_report(logits, ref_logits):
@@ -132,7 +138,7 @@ def protocol_test(args):
                           "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
                           "value": round(world * args.batch * args.seq_len * args.steps / elapsed, 1),
                           "scaling": "weak", "per_rank_ms_per_step": list(PER_RANK_MS),
-                          "config": {"workload": "protocol-test", "ln_fold": os.environ.get("ESM_AMD_LN_FOLD", "library default (off)")},
+                          "config": {"workload": "protocol-test", "ln_fold": os.environ.get("ESM_AMD_LN_FOLD", "library default (on)")},
                           "backend": dist.get_backend() if dist is not None else None,
                           "launched_by": os.environ.get("ESM_AMD_BENCH_LAUNCH", "external-or-single")}), flush=True)
     finish(dist)
@@ -168,34 +174,31 @@ def class_table(prof, prof_steps):
 PMC_CLASS = {"gemm_qkv_rope": "gemm_qkv_rope(qk)"}
 
 
-def pmc_traffic(kernel_class, src_hash, workload="esm2_650m"):
-    """HBM bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes of that workload (tools/
-    profile_bench.sh -> profiles/r4_pmc_summary*.json; FETCH_SIZE doubled as the microarch guide prescribes for
-    gfx950).  The summary records the source hash of the library it profiled: a different build -> null (never a
-    stale number), unless profiles/r4_isa_equivalence.json names it as identical, kernel by kernel, in everything the bench
-    workloads launch (then the source string carries both hashes and the evidence file)."""
+def pmc_traffic(kernel_class, src_hash, workload="esm2_650m", batch=None, ln_fold=None):
+    """HBM bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes (tools/profile_bench.sh ->
+    profiles/r5_pmc_summary_*.json; FETCH_SIZE doubled as the microarch guide prescribes for gfx950).  A figure is
+    reported ONLY when a summary exists for exactly this (workload, per-GPU batch, LayerNorm-fold mode) AND records the
+    source hash of the library that is running — anything else is null with the reason (never a stale number, never
+    another launch shape's number: VERDICT r4 Weak-6)."""
+    batch = batch or DEFAULT_BATCH.get(workload)
+    path = pmc_summary_path(workload, batch, ln_fold)
+    rel = os.path.relpath(path, ROOT)
     try:
-        with open(PMC_SUMMARY[workload]) as f:
+        with open(path) as f:
             s = json.load(f)
-        also = ""
+    except OSError:
+        return None, f"no PMC summary for workload {workload}, batch {batch}, ln_fold {ln_fold} ({rel} missing)"
+    try:
         if s.get("library_src_hash") != src_hash:
-            # a different build: accepted only if the committed ISA comparison lists it as identical in every kernel these
-            # workloads launch — and the source string says so; anything else -> null (never a stale number)
-            try:
-                with open(ISA_EQUIVALENCE) as f:
-                    eq = json.load(f).get(s.get("library_src_hash"), {}).get(src_hash)
-            except OSError:
-                eq = None
-            if not eq:
-                return None, f"PMC summary is from build {s.get('library_src_hash')}, this is {src_hash}"
-            also = (f"; this library {src_hash} differs from it only in {eq['differs_in']}, which no bench workload's reported "
-                    f"kernel class launches: {eq['evidence']}")
-        # where the number comes from: the committed summary file + the hash of the library it profiled
+            return None, f"{rel} is from build {s.get('library_src_hash')}, this is {src_hash}"
+        if s.get("workload") != workload or s.get("batch") != batch or bool(s.get("ln_fold")) != bool(ln_fold):
+            return None, (f"{rel} was taken at workload {s.get('workload')}, batch {s.get('batch')}, ln_fold {s.get('ln_fold')}; "
+                          f"this run is {workload}, batch {batch}, ln_fold {ln_fold}")
         return (s["kernels"][kernel_class]["hbm_bytes_corrected"],
-                f"{os.path.relpath(PMC_SUMMARY[workload], os.path.dirname(os.path.abspath(__file__)))} (rocprofv3 PMC passes of library "
-                f"{s.get('library_src_hash')}" + (f", commit {s['git_sha']}" if s.get("git_sha") else "") + also + ")")
-    except Exception as e:  # missing file / class
-        return None, str(e)
+                f"{rel} (rocprofv3 PMC passes of library {s['library_src_hash']}, batch {batch}, ln_fold {bool(ln_fold)}"
+                + (f", commit {s['git_sha']}" if s.get("git_sha") else "") + ")")
+    except Exception as e:  # missing class / malformed file
+        return None, f"{rel}: {type(e).__name__}: {e}"
 
 
 def mfma_roofline(prof, name=None):
@@ -228,13 +231,22 @@ def profile_steps(model, step, prof_steps=2):
     return model.profile_end(), prof_steps
 
 
-def base_result(args, world, metric, value, elapsed, workload, extra_cfg):
+def fold_state(model):
+    """'on' / 'off' as the ENGINE reports it (esmk_ln_fold_enabled), plus who decided."""
+    act = getattr(model, "ln_fold_active", lambda: None)()
+    env = os.environ.get("ESM_AMD_LN_FOLD")
+    return {"active": act, "label": ("on" if act else "off" if act is not None else "n/a (no fold in this engine)")
+                                    + (f" (ESM_AMD_LN_FOLD={env})" if env is not None else " (library default)")}
+
+
+def base_result(args, world, metric, value, elapsed, workload, extra_cfg, model=None):
+    fs = fold_state(model) if model is not None else {"active": None, "label": "n/a"}
+    extra_cfg = dict(extra_cfg, ln_fold=fs["label"])
     return {
         "metric": metric, "value": round(value, 1), "unit": "residues/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": getattr(args, "scaling", "weak"), "vs_baseline": None, "dtype": operand_name(), "data": "synthetic",
-        "config": {"workload": workload, "sharding": f"dp{world} (no data-path collective)",
-                   "ln_fold": os.environ.get("ESM_AMD_LN_FOLD", "library default (off)"), **extra_cfg},
+        "config": {"workload": workload, "sharding": f"dp{world} (no data-path collective)", **extra_cfg},
         "host_cores": os.cpu_count(), "per_rank_ms_per_step": list(PER_RANK_MS),
     }
 
@@ -309,18 +321,24 @@ def run_esm2_650m(args, dist, rank, world, dev):
     result = base_result(
         args, world, "residues/sec (whole node) ESM-2 650M L=1022 bulk extract", value, elapsed,
         f"{MODEL} forward (repr_layers=[33] + logits), synthetic tokens [B,{args.seq_len + 2}], random-init weights "
-        "of the 650M architecture", {"batch_per_gpu": batch, "seq_len": args.seq_len})
+        "of the 650M architecture", {"batch_per_gpu": batch, "seq_len": args.seq_len}, model)
     build = library_build()
+    fold_on = model.ln_fold_active()
+    traffic = lambda cls: pmc_traffic(cls, build["src_hash"], "esm2_650m", batch, fold_on)
     dom, roof = mfma_roofline(prof)
-    roof["traffic"], roof["traffic_source"] = pmc_traffic(dom["name"], build["src_hash"])
+    roof["traffic"], roof["traffic_source"] = traffic(dom["name"])
     result["e2e_mfma_frac_per_gpu"] = round(value / world * FLOP_PER_RESIDUE / (MFMA_PEAK_TFLOPS * 1e12), 4)
     result["roofline"] = roof
     _, ra = mfma_roofline(prof, "attention")
-    ra["traffic"], _ = pmc_traffic("attention", build["src_hash"])
+    ra["traffic"], _ = traffic("attention")
     result["roofline_attention"] = ra
+    # the HBM-bound kernel of the step: the standalone LayerNorm passes (plain mode: 66 per step; with the fold only the
+    # row-statistics entry, the per-layer finalize launches and the final LayerNorm are left in this class)
     rh = hbm_roofline(prof)
     if rh is not None:
-        rh["traffic"], _ = pmc_traffic("layernorm", build["src_hash"])
+        rh["traffic"], _ = traffic("layernorm")
+        rh["note"] = ("LayerNorm fold on: this class holds rowstats + ln_finalize + the final LayerNorm only" if fold_on
+                      else "standalone LayerNorm passes, 2 per layer")
     result["roofline_hbm"] = rh
     result["kernel_classes"] = class_table(prof, prof_steps)
     result["profiled_ms_per_step"] = round(sum(e["ms"] for e in prof) / prof_steps, 3)
@@ -331,6 +349,21 @@ def run_esm2_650m(args, dist, rank, world, dev):
                                     "side stream, overlapped with the next forward"}
     result["library"] = build
 
+    if world == 1 and args.parity_ref and os.path.exists(args.parity_ref):
+        # a secondary line of the default run: parity of THIS engine configuration on the parent's 4 sample sequences,
+        # against the oracle outputs the parent computed once (bench.py secondary_workloads)
+        try:
+            pr = torch.load(args.parity_ref)
+            with torch.no_grad():
+                got = model(pr["tokens"].to(dev), repr_layers=[L])
+            r_gpu, r_ref = got["representations"][L].cpu().double(), pr["repr"].double()
+            max_abs = (r_gpu - r_ref).abs().max().item()
+            result["parity"] = {"max_abs_repr_diff_vs_cpu": max_abs, "rel_repr_diff_vs_cpu": max_abs / r_ref.abs().max().item(),
+                                "rel_l2_repr_diff_vs_cpu": ((r_gpu - r_ref).norm() / r_ref.norm()).item(),
+                                **argmax_report(got["logits"].float().cpu(), pr["logits"].float()), "sample_sequences": 4,
+                                "reference": "fp32 oracle outputs of the parent run on the same 4 sequences"}
+        except Exception as e:
+            result["parity"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     if world == 1 and not args.no_cpu_baseline:
         from oracle.esm2_oracle import esm2_forward
 
@@ -370,6 +403,8 @@ def run_esm2_650m(args, dist, rank, world, dev):
             **amax, "sample_sequences": 4,
         }
         result["parity"]["operand_floor_same_inputs"] = operand_floor_report(sd, s4, L, H, r_ref)
+        if args.save_parity_ref:  # for the secondary 650M lines (other batch / fold settings): same sequences, same reference
+            torch.save({"tokens": s4, "repr": ref["representations"][L], "logits": ref["logits"]}, args.save_parity_ref)
     return result
 
 
@@ -399,18 +434,22 @@ SECONDARY = [  # --quick-baseline: the children's own CPU-oracle sample (parity 
     ("msa1b", ["--workload", "msa1b", "--quick-baseline"], 120),
     ("extract_650m", ["--workload", "extract_650m", "--steps", "8", "--warmup", "2", "--quick-baseline"], 150),
     ("esm2_3b_contacts", ["--workload", "esm2_3b_contacts", "--steps", "4", "--quick-baseline"], 200),
-    # the reference script's default token budget (scripts/extract.py:36: 4096 tokens = 4 sequences of L = 1022), plain and
-    # with the LayerNorm fold (the fold pays at small batches)
-    ("esm2_650m_b4", ["--workload", "esm2_650m", "--batch", "4", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-secondary"], 60),
-    ("esm2_650m_b4_ln_fold", ["--workload", "esm2_650m", "--batch", "4", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
-                              "--no-secondary", "--ln-fold", "1"], 60),
+    # the headline configuration WITHOUT the LayerNorm fold (round 4's default path), same run, same box
+    ("esm2_650m_plain", ["--workload", "esm2_650m", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-secondary",
+                         "--ln-fold", "0", "--parity-ref", "{PARITY_REF}"], 90),
+    # the reference script's default token budget (scripts/extract.py:36: 4096 tokens = 4 sequences of L = 1022), default mode
+    # and without the fold
+    ("esm2_650m_b4", ["--workload", "esm2_650m", "--batch", "4", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-secondary",
+                      "--parity-ref", "{PARITY_REF}"], 60),
+    ("esm2_650m_b4_plain", ["--workload", "esm2_650m", "--batch", "4", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                            "--no-secondary", "--ln-fold", "0", "--parity-ref", "{PARITY_REF}"], 60),
 ]
 T_PROCESS_START = time.perf_counter()
-SECONDARY_BUDGET_S = 180.0  # the default run, children included, ends within ~3 minutes of its start
+SECONDARY_BUDGET_S = 230.0  # the default run, children included, ends within ~4 minutes of its start
 SECONDARY_MIN_S = 30.0      # a child is not started with less than this left
 
 
-def secondary_workloads(extra=(), budget_end=None):
+def secondary_workloads(extra=(), budget_end=None, parity_ref=""):
     import subprocess
 
     if budget_end is None:
@@ -429,6 +468,7 @@ def secondary_workloads(extra=(), budget_end=None):
             out[name] = {"skipped": "time budget of the default run spent (run it with --workload " + name + ")"}
             continue
         try:
+            argv = [a.replace("{PARITY_REF}", parity_ref) for a in argv]
             p = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv + list(extra), capture_output=True,
                                text=True, timeout=limit, env=env)
             lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -479,33 +519,52 @@ def run_esm2_3b_contacts(args, dist, rank, world, dev):
     result = base_result(
         args, world, "residues/sec ESM-2 3B L=1022 contact prediction (predict_contacts)", value, elapsed,
         f"{MODEL} predict_contacts(tokens [B,{T}]): 36-layer forward + contact head without the [B,L,H,T,T] tensor, "
-        "random-init weights of the 3B architecture", {"batch_per_gpu": batch, "seq_len": args.seq_len})
+        "random-init weights of the 3B architecture", {"batch_per_gpu": batch, "seq_len": args.seq_len}, model)
     result["e2e_mfma_frac_per_gpu"] = round(value / world / args.seq_len * flop_per_seq / (MFMA_PEAK_TFLOPS * 1e12), 4)
     dom, result["roofline"] = mfma_roofline(prof)
     result["roofline_hbm"] = hbm_roofline(prof)
     result["kernel_classes"] = class_table(prof, prof_steps)
     result["library"] = library_build()
     result["roofline"]["traffic"], result["roofline"]["traffic_source"] = pmc_traffic(
-        PMC_CLASS.get(dom["name"], dom["name"]), result["library"]["src_hash"], "esm2_3b_contacts")
+        PMC_CLASS.get(dom["name"], dom["name"]), result["library"]["src_hash"], "esm2_3b_contacts", batch, model.ln_fold_active())
     if world == 1 and not args.no_cpu_baseline:
-        from oracle.esm2_oracle import esm2_forward
+        from oracle.esm2_oracle import ALL_OPERANDS, esm2_forward
 
         ncores = cpu_threads()
-        n_small = 128 if args.quick_baseline else 256
-        small = synth_tokens(1, n_small, seed=5)  # bounded sample: the oracle materialises [1440,T,T] four times
+        # T = 258 — the length of the committed config-3 fixture (tests/golden/large_esm2_3b_T258.pt), also under
+        # --quick-baseline: a 128-residue sample read ~15 % friendlier than the fixture.  The oracle
+        # materialises [1440,T,T] four times: ~1.5 GB, seconds on 32 threads.
+        n_small = 256
+        small = synth_tokens(1, n_small, seed=5)
         c0 = time.perf_counter()
         ref = esm2_forward(sd, small, L, H, repr_layers=[L], return_contacts=True)
         t_cpu = time.perf_counter() - c0
         with torch.no_grad():
+            out = model(small.to(dev), repr_layers=[L])
             got = model.predict_contacts(small.to(dev)).cpu()
         lg = lambda t: torch.logit(t.double().clamp(1e-12, 1 - 1e-12))
         z, zr = lg(got), lg(ref["contacts"])
+        r_gpu, r_ref = out["representations"][L].cpu().double(), ref["representations"][L].double()
         result["cpu_baseline"] = {"value": round(n_small / t_cpu, 1), "unit": "residues/s", "cores": ncores,
                                   "host_cores": os.cpu_count(), "kind": "port",
-                                  "sample": f"one sequence of {n_small} residues through the fp32 oracle with contacts, 1 run"}
+                                  "sample": f"one sequence of {n_small} residues (T = {n_small + 2}) through the fp32 oracle with contacts, 1 run"}
         result["parity"] = {"contacts_max_abs_prob_diff": (got - ref["contacts"]).abs().max().item(),
                             "contacts_max_abs_logit_diff": (z - zr).abs().max().item(),
-                            "contacts_logit_diff_rel_to_range": ((z - zr).abs().max() / zr.abs().max()).item()}
+                            "contacts_logit_diff_rel_to_range": ((z - zr).abs().max() / zr.abs().max()).item(),
+                            "rel_repr_diff_vs_cpu": ((r_gpu - r_ref).abs().max() / r_ref.abs().max()).item(),
+                            "rel_l2_repr_diff_vs_cpu": ((r_gpu - r_ref).norm() / r_ref.norm()).item(),
+                            **argmax_report(out["logits"].float().cpu(), ref["logits"].float()), "sample_residues": n_small}
+        try:  # the fp16-operand floor on the same sample: what any 16-bit-operand engine gets at best
+            fl = esm2_forward(sd, small, L, H, repr_layers=[L], return_contacts=True, inject=(frozenset(ALL_OPERANDS), torch.float16))
+            zf = lg(fl["contacts"])
+            f_rep = fl["representations"][L].double()
+            result["parity"]["operand_floor_same_inputs"] = {
+                "contacts_logit_diff_rel_to_range": ((zf - zr).abs().max() / zr.abs().max()).item(),
+                "rel_repr_diff_vs_cpu": ((f_rep - r_ref).abs().max() / r_ref.abs().max()).item(),
+                "rel_l2_repr_diff_vs_cpu": ((f_rep - r_ref).norm() / r_ref.norm()).item(),
+                "logits_rel_diff": ((fl["logits"] - ref["logits"]).abs().max() / ref["logits"].abs().max()).item()}
+        except Exception as e:
+            result["parity"]["operand_floor_same_inputs"] = {"error": str(e)[:200]}
     return result
 
 
@@ -545,7 +604,7 @@ def run_msa1b(args, dist, rank, world, dev):
     result = base_result(
         args, world, "MSA residues/sec esm_msa1b_t12_100M 128-seq MSA L=512", value, elapsed,
         f"esm_msa1b_t12_100M dims (12 x 768, 12 heads): model(tokens [{batch},{R},{C}], repr_layers=[12]) — tied row "
-        "attention + column attention + FFN, random-init weights", {"msas_per_gpu": batch, "rows": R, "cols": C})
+        "attention + column attention + FFN, random-init weights", {"msas_per_gpu": batch, "rows": R, "cols": C}, model)
     result["e2e_mfma_frac_per_gpu"] = round(flop * args.steps / elapsed / (MFMA_PEAK_TFLOPS * 1e12), 4)
     result["tflops_algorithmic"] = round(flop * args.steps / elapsed / 1e12, 1)
     dom, result["roofline"] = mfma_roofline(prof)
@@ -553,7 +612,7 @@ def run_msa1b(args, dist, rank, world, dev):
     result["kernel_classes"] = class_table(prof, prof_steps)
     result["library"] = library_build()
     result["roofline"]["traffic"], result["roofline"]["traffic_source"] = pmc_traffic(
-        PMC_CLASS.get(dom["name"], dom["name"]), result["library"]["src_hash"], "msa1b")
+        PMC_CLASS.get(dom["name"], dom["name"]), result["library"]["src_hash"], "msa1b", batch, None)
     if world == 1 and not args.no_cpu_baseline:
         from oracle.msa_oracle import msa_forward
 
@@ -669,7 +728,7 @@ def run_extract_650m(args, dist, rank, world, dev):
         "esm_amd.extract.extract on synthetic FASTA strings: tokenise -> esm2_t33_650M forward -> device->host -> "
         "one .pt per sequence (--include mean per_tok, reference file format)",
         {"batch_per_gpu": batch, "seq_len": args.seq_len, "output_fs": str(base),
-         "writer_threads": args.writer_threads or default_writer_threads()})
+         "writer_threads": args.writer_threads or default_writer_threads()}, model)
     result["files_written_this_rank"] = n_files
     result["file_gb_per_s_this_rank"] = round(nbytes / elapsed / 1e9 * args.steps / (args.steps + max(args.warmup, 1)), 3)
     result["e2e_mfma_frac_per_gpu"] = round(value / world * 1.4769e9 / (MFMA_PEAK_TFLOPS * 1e12), 4)
@@ -709,11 +768,15 @@ def main():
     ap.add_argument("--writer-threads", type=int, default=0, help="extract_650m: writer threads (0 = from host cores)")
     ap.add_argument("--ln-fold", type=int, choices=[0, 1], default=None,
                     help="LayerNorm fold of the engine (esmk_config.ln_fold, DESIGN.md 4.8): 1 = the per-layer LayerNorm passes "
-                         "become GEMM epilogue work (faster at small batches, slower at B = 64), 0 = off (the library default)")
+                         "become GEMM epilogue work (the library default since round 5: faster at every batch size), 0 = off")
     ap.add_argument("--operand", choices=["f16", "bf16", "f16x2"], default=None,
                     help="MFMA operand type (default f16; bf16 is ~4 %% faster at ~7e-3 relative error; f16x2 = fp16 with "
                          "split weights W = W_hi + W_lo: 2x GEMM time, ~40 %% lower error — the precision mode with "
                          "margin under the 1e-3 contract).  Sets ESM_AMD_OPERAND for this run.")
+    ap.add_argument("--parity-ref", default="", help="esm2_650m: file with {tokens, repr, logits} of the fp32 oracle on 4 sample "
+                                                       "sequences (written by the default run for its secondary lines): report "
+                                                       "`parity` of this configuration against it")
+    ap.add_argument("--save-parity-ref", default="", help=argparse.SUPPRESS)
     ap.add_argument("--spawn", action="store_true",
                     help="go through the self-launch path even for --gpus 1 (tests: the N = 1 run then initialises RCCL "
                          "exactly as an N > 1 run does)")
@@ -739,16 +802,28 @@ def main():
     dist, rank, world, local_rank = init_ranks(args.gpus, "nccl")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    result = WORKLOADS[args.workload](args, dist, rank, world, dev)
-    if rank == 0:
-        result["collective_backend"] = dist.get_backend() if dist is not None else None
-        if world == 1 and args.workload == "esm2_650m" and not (args.no_cpu_baseline or args.no_secondary):
-            try:
-                torch.cuda.empty_cache()
-                result["secondary_workloads"] = secondary_workloads()
-            except Exception as e:  # belt and braces: the flagship line is printed whatever happens here
-                result["secondary_workloads"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        print(json.dumps(result), flush=True)
+    with_secondary = world == 1 and args.workload == "esm2_650m" and not (args.no_cpu_baseline or args.no_secondary)
+    ref_file = None
+    if with_secondary and not args.save_parity_ref:
+        import tempfile
+
+        fd, ref_file = tempfile.mkstemp(prefix="esm_amd_parity_ref_", suffix=".pt")
+        os.close(fd)
+        args.save_parity_ref = ref_file
+    try:
+        result = WORKLOADS[args.workload](args, dist, rank, world, dev)
+        if rank == 0:
+            result["collective_backend"] = dist.get_backend() if dist is not None else None
+            if with_secondary:
+                try:
+                    torch.cuda.empty_cache()
+                    result["secondary_workloads"] = secondary_workloads(parity_ref=ref_file or "")
+                except Exception as e:  # belt and braces: the flagship line is printed whatever happens here
+                    result["secondary_workloads"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            print(json.dumps(result), flush=True)
+    finally:
+        if ref_file and os.path.exists(ref_file):
+            os.remove(ref_file)
     finish(dist)
 
 

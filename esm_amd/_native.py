@@ -94,6 +94,7 @@ SIGNATURES = {
     ),
     "esmk_profile_begin": (c_int, [c_void_p]),
     "esmk_profile_end": (c_int, [c_void_p, POINTER(EsmkProfileEntry), c_int, POINTER(c_int)]),
+    "esmk_ln_fold_enabled": (c_int, [c_void_p]),
     "esmk_op_layernorm": (
         c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "esmk_op_masked_row_mean": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -38,6 +38,8 @@
 #include "kernels.h"
 #include <math.h>
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 
 namespace esmk {
@@ -474,7 +476,7 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
 
 // start-up stagger of the co-resident workgroups in shader cycles per wave slot (attn_fwd_kernel); < 0 = read
 // ESMK_ATTN_STAGGER on the first launch; esmk_debug_set("attn_stagger", cycles)
-static int g_attn_stagger = -1;
+static std::atomic<int> g_attn_stagger{-1};
 constexpr int kAttnStaggerDefault = 0;
 void attention_set_stagger(int cycles) { g_attn_stagger = cycles < 0 ? 0 : cycles; }
 
@@ -512,11 +514,14 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
         const char* e = getenv("ESMK_ATTN");
         return e ? atoi(e) : ATTN_DEFAULT_VARIANT;
     }();
-    if (g_attn_stagger < 0) {
-        const char* e = getenv("ESMK_ATTN_STAGGER");
-        g_attn_stagger = e ? atoi(e) : kAttnStaggerDefault;
-    }
-    const int stagger = g_attn_stagger;
+    static std::once_flag stagger_once;  // launches may come from several host threads
+    std::call_once(stagger_once, [] {
+        if (g_attn_stagger.load() < 0) {
+            const char* e = getenv("ESMK_ATTN_STAGGER");
+            g_attn_stagger = e ? atoi(e) : kAttnStaggerDefault;
+        }
+    });
+    const int stagger = g_attn_stagger.load();
 #define ESMK_ATTN_LAUNCH(TT, LZ, BF, ...)                                                                      \
     hipLaunchKernelGGL((attn_fwd_kernel<TT, LZ, BF, ##__VA_ARGS__>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k,   \
                        (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad, segs, stagger)
@@ -524,14 +529,22 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
         if (var & 2) ESMK_ATTN_LAUNCH(__bf16, 0, true);
         else ESMK_ATTN_LAUNCH(__bf16, 1, true);
     } else {
+#ifdef ESMK_EXPERIMENTS  // parts of the kernel removed (results wrong): experiment builds only (common.h)
         static const int hack = [] { const char* e = getenv("ESMK_ATTN_HACK"); return e ? atoi(e) : 0; }();
-        if (hack == 1) ESMK_ATTN_LAUNCH(_Float16, 1, true, 1);
-        else if (hack == 2) ESMK_ATTN_LAUNCH(_Float16, 1, true, 2);
-        else if (hack == 3) ESMK_ATTN_LAUNCH(_Float16, 1, true, 3);
-        else if (hack == 4) ESMK_ATTN_LAUNCH(_Float16, 1, true, 4);
-        else if (hack == 8) ESMK_ATTN_LAUNCH(_Float16, 1, true, 8);
-        else if (hack == 12) ESMK_ATTN_LAUNCH(_Float16, 1, true, 12);
-        else if (var & 2) ESMK_ATTN_LAUNCH(_Float16, 0, true);
+#else
+        constexpr int hack = 0;
+#endif
+        if (hack != 0) {
+#ifdef ESMK_EXPERIMENTS
+            if (hack == 1) ESMK_ATTN_LAUNCH(_Float16, 1, true, 1);
+            else if (hack == 2) ESMK_ATTN_LAUNCH(_Float16, 1, true, 2);
+            else if (hack == 3) ESMK_ATTN_LAUNCH(_Float16, 1, true, 3);
+            else if (hack == 4) ESMK_ATTN_LAUNCH(_Float16, 1, true, 4);
+            else if (hack == 8) ESMK_ATTN_LAUNCH(_Float16, 1, true, 8);
+            else if (hack == 12) ESMK_ATTN_LAUNCH(_Float16, 1, true, 12);
+            else return hipErrorInvalidValue;
+#endif
+        } else if (var & 2) ESMK_ATTN_LAUNCH(_Float16, 0, true);
         else if (var & 8) ESMK_ATTN_LAUNCH(_Float16, 1, false);
         else ESMK_ATTN_LAUNCH(_Float16, 1, true);
     }

@@ -16,8 +16,10 @@ using namespace esmk;
 using namespace esmk_host;
 
 static constexpr float kLog2e = 1.4426950408889634f;
-// LayerNorm fold for handles created with esmk_config::ln_fold == 0 and no ESMK_LN_FOLD in the environment
-static constexpr bool kLnFoldDefault = false;
+// LayerNorm fold for handles created with esmk_config::ln_fold == 0 and no ESMK_LN_FOLD in the environment:
+// ON since round 5 wherever the configuration supports it (plain fp16 / bf16 operands, head_dim <= 64) — faster at every
+// batch size (B = 64 + 1.1 %, B = 4 + 6.5 %) and on the fp16-operand floor numerically, like the plain mode
+static constexpr bool kLnFoldDefault = true;
 
 namespace {
 thread_local std::string g_err;
@@ -419,7 +421,19 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
         // LayerNorm fold: q/k/v and fc1 weights are packed as gamma-folded, row-centred images + W . beta (bias2); the
         // LayerNorm parameters they fold must be in the image already, and packing one of those later marks the folded
         // weights stale (esmk_forward refuses to run on a stale fold)
+        if (m->fold && m->fold_image != packed_dev) {  // another image: its folds start unpacked
+            m->fold_state.assign(m->L, 0u);
+            m->fold_image = packed_dev;
+        }
         uint32_t& fs = m->fold_state[l];
+        // LayerNorm parameter of a fold: the "present" bit is set only once the copy was queued; the folded weights that
+        // depend on it are stale from the moment the call is made, whether or not it succeeds
+        auto ln_put = [&](size_t off, uint32_t present, uint32_t stale) -> int {
+            fs &= ~(stale | present);
+            if (put(off, ESMK_DT_F32, E)) return 1;
+            fs |= present;
+            return 0;
+        };
         auto fold_put = [&](size_t woff, size_t b2off, size_t rows, int rmap, size_t lng, size_t lnb, uint32_t need,
                             uint32_t done) -> int {
             if ((fs & need) != need)
@@ -438,10 +452,10 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
             if (!strcmp(sub, "self_attn.k_proj.weight")) return fold_put(o.wqkv + EA * Kp * os, o.bqkv2 + EA * 4, E, qkmap, o.ln1g, o.ln1b, FB_LN1G | FB_LN1B, FB_WK);
             if (!strcmp(sub, "self_attn.v_proj.weight")) return fold_put(o.wqkv + 2 * EA * Kp * os, o.bqkv2 + 2 * EA * 4, E, padmap, o.ln1g, o.ln1b, FB_LN1G | FB_LN1B, FB_WV);
             if (!strcmp(sub, "fc1.weight")) return fold_put(o.w1, o.b12, F, 0, o.ln2g, o.ln2b, FB_LN2G | FB_LN2B, FB_W1);
-            if (!strcmp(sub, "self_attn_layer_norm.weight")) { fs = (fs | FB_LN1G) & ~(FB_WQ | FB_WK | FB_WV); return put(o.ln1g, ESMK_DT_F32, E); }
-            if (!strcmp(sub, "self_attn_layer_norm.bias")) { fs = (fs | FB_LN1B) & ~(FB_WQ | FB_WK | FB_WV); return put(o.ln1b, ESMK_DT_F32, E); }
-            if (!strcmp(sub, "final_layer_norm.weight")) { fs = (fs | FB_LN2G) & ~FB_W1; return put(o.ln2g, ESMK_DT_F32, E); }
-            if (!strcmp(sub, "final_layer_norm.bias")) { fs = (fs | FB_LN2B) & ~FB_W1; return put(o.ln2b, ESMK_DT_F32, E); }
+            if (!strcmp(sub, "self_attn_layer_norm.weight")) return ln_put(o.ln1g, FB_LN1G, FB_WQ | FB_WK | FB_WV);
+            if (!strcmp(sub, "self_attn_layer_norm.bias")) return ln_put(o.ln1b, FB_LN1B, FB_WQ | FB_WK | FB_WV);
+            if (!strcmp(sub, "final_layer_norm.weight")) return ln_put(o.ln2g, FB_LN2G, FB_W1);
+            if (!strcmp(sub, "final_layer_norm.bias")) return ln_put(o.ln2b, FB_LN2B, FB_W1);
         }
         // q/k/v: output rows are head dims -> spread over 64 slots; input columns padded to Kp
         if (!strcmp(sub, "self_attn.q_proj.weight")) return putw(o.wqkv, E, E, Kp, qkmap, 0);
@@ -686,6 +700,9 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
     // LayerNorm fold: hA = raw rows of the residual stream in the operand dtype (written by rowstats for
     // layer 0, then by the residual epilogues), hB = attention context; without the fold both are `h`
     const bool fold = m->fold;
+    if (fold && m->fold_image != packed_dev)
+        return fail("esmk_forward: LayerNorm fold: this packed image is not the one the handle's weights were last packed "
+                    "into (one image per handle at a time: re-pack, or use a second handle)");
     if (fold)
         for (int l = 0; l < L; ++l)
             if ((m->fold_state[l] & FB_ALL_W) != FB_ALL_W)
@@ -704,7 +721,7 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         a.ln_mean = ln_mean;
     };
     auto finalize = [&]() -> int {
-        ProfScope ps(m, st, PC_LAYERNORM, 4.0 * N * w.ln_parts, (double)N * (8.0 * w.ln_parts + 12));
+        ProfScope ps(m, st, PC_LN_STATS, 4.0 * N * w.ln_parts, (double)N * (8.0 * w.ln_parts + 12));
         ESMK_TRY(launch_ln_finalize(ln_part, ln_mean, ln_rstd, N, w.ln_parts, E, st));
         return 0;
     };
@@ -775,7 +792,7 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         if (!fold) {
             if (lnorm(x, o.ln1g, o.ln1b, h, nullptr)) return 1;
         } else if (l == 0) {  // entry of the fold chain: rows and statistics of the embedded stream
-            ProfScope ps(m, st, PC_LAYERNORM, 8 * NE, NE * (4 + os));
+            ProfScope ps(m, st, PC_LN_STATS, 8 * NE, NE * (4 + os));
             ESMK_TRY(launch_rowstats(x, hA, ln_mean, ln_rstd, N, E, Kp, op, st));
         }
         g = GemmArgs();
@@ -982,6 +999,8 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
     }
     return 0;
 }
+
+int esmk_ln_fold_enabled(const esmk_model* m) { return (!m || m->is_msa) ? -1 : (m->fold ? 1 : 0); }
 
 int esmk_profile_begin(esmk_model* m) {
     if (!m) return fail("esmk_profile_begin: null model");

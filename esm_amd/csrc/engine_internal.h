@@ -90,6 +90,9 @@ struct esmk_model {
     // packed, and which folded images are current (a LayerNorm parameter packed after its weights makes them stale).
     bool fold = false;
     std::vector<uint32_t> fold_state;
+    // the packed image fold_state describes: the bits belong to ONE caller-owned image, so packing into (or running
+    // on) another image starts from "nothing packed" instead of inheriting the previous image's bits
+    const void* fold_image = nullptr;
     // MSA Transformer (esmk_msa_create)
     bool is_msa = false;
     int npos = 0, has_msa_pos = 0;
@@ -104,12 +107,15 @@ struct esmk_model {
 enum {
     PC_EMBED = 0, PC_LAYERNORM, PC_GEMM_QKV, PC_ATTENTION, PC_ATTN_PROBS, PC_GEMM_OUT, PC_GEMM_FC1,
     PC_GEMM_FC2, PC_COPY, PC_LM_DENSE, PC_LM_LOGITS, PC_CONTACTS,
-    PC_MSA_ROW_SCORES, PC_MSA_ROW_SOFTMAX, PC_MSA_ROW_CTX, PC_MSA_COL_ATTN, PC_COUNT
+    PC_MSA_ROW_SCORES, PC_MSA_ROW_SOFTMAX, PC_MSA_ROW_CTX, PC_MSA_COL_ATTN, PC_LN_STATS, PC_COUNT
 };
 static const char* const kProfNames[PC_COUNT] = {
     "embed", "layernorm", "gemm_qkv_rope", "attention", "attention_probs", "gemm_out_proj",
     "gemm_fc1_gelu", "gemm_fc2", "repr_copy", "lm_head_dense", "lm_head_logits", "contacts",
-    "msa_row_scores", "msa_row_softmax", "msa_row_context", "msa_col_attention"};
+    "msa_row_scores", "msa_row_softmax", "msa_row_context", "msa_col_attention",
+    // LayerNorm fold: the row-statistics entry pass and the per-LayerNorm finalize launches (tiny; the LayerNorm passes
+    // themselves are GEMM epilogue work) — "layernorm" keeps the standalone LayerNorm kernel (with the fold: the final one)
+    "ln_fold_stats"};
 
 // Brackets one launch with two events on the launch stream when profiling is enabled.
 struct ProfScope {

@@ -29,6 +29,7 @@
 // per-element predicated stores; used for shapes the fast kernel does not cover
 // (K % 64 != 0, N % 4 != 0 such as the 33-wide vocabulary projection).
 #include "gemm_epi.h"
+#include <atomic>
 #include <mutex>
 #include <stdlib.h>
 #include <string.h>
@@ -318,7 +319,8 @@ static hipError_t dispatch(const GemmArgs& p, int epi, hipStream_t st) {
         return epi == EPI_V_T ? launch_fast<T, EPI_V_T>(p, st) : launch_fast<T, EPI_QKV_ROPE>(p, st);
     }
     if (!fast && (p.K % 32 != 0)) return hipErrorInvalidValue;
-    if (p.dbg && fast && epi == EPI_STORE_T) {  // timing experiments
+#ifdef ESMK_EXPERIMENTS
+    if (p.dbg && fast && epi == EPI_STORE_T) {  // timing experiments (results wrong)
         switch (p.dbg) {
             case 1: return launch_fast<T, EPI_STORE_T, 1>(p, st);
             case 2: return launch_fast<T, EPI_STORE_T, 2>(p, st);
@@ -336,6 +338,9 @@ static hipError_t dispatch(const GemmArgs& p, int epi, hipStream_t st) {
             case 160: return launch_fast<T, EPI_STORE_T, 160>(p, st);
         }
     }
+#else
+    if (p.dbg) return hipErrorInvalidValue;
+#endif
 #define ESMK_CASE(E)                                               \
     case E:                                                        \
         return fast ? launch_fast<T, E>(p, st) : launch_generic<T, E>(p, st);
@@ -366,32 +371,32 @@ void gemm_set_impl(int impl, int var) {
 
 // Start-up delay of one workgroup group in the residual GEMMs (gemm9.hip), as a fraction of a tile's main loop
 // (nk K tiles x ~2700 cycles); < 0 = not read yet (ESMK_RESID_DESYNC / ESMK_RESID_DESYNC_GROUP, esmk_debug_set).
-static int g_lnf_dbg = 0;
-static int g_qkv_one = -2;  // -2: not set (environment decides)
-static double g_desync = -1.0;
-static int g_desync_group = -1;
+// Knobs: atomics, so that a launch thread never reads a half-initialised value; their environment defaults are read inside
+// gemm_env_init's call_once like every other ESMK_GEMM_* variable (launches may come from several host threads).
+static std::atomic<int> g_lnf_dbg{0};
+static std::atomic<int> g_qkv_one{-2};  // -2: not set (environment decides)
+static std::atomic<int> g_qkv_one_env{-1};
+static std::atomic<double> g_desync{-1.0};
+static std::atomic<int> g_desync_group{-1};
 constexpr double kDesyncDefault = 0.0;
 bool gemm_set_knob(const char* key, double value) {
     if (strcmp(key, "resid_desync") == 0) g_desync = value < 0 ? 0.0 : value;
     else if (strcmp(key, "resid_desync_group") == 0) g_desync_group = (int)value;
-    else if (strcmp(key, "lnf_dbg") == 0) g_lnf_dbg = (int)value;
-    else if (strcmp(key, "qkv_one_launch") == 0) g_qkv_one = (int)value < -1 ? -2 : (int)value;
+    else if (strcmp(key, "lnf_dbg") == 0) {
+        if (!kExperiments && (int)value != 0) return false;  // removes parts of the producer epilogue: ESMK_EXPERIMENTS builds only
+        g_lnf_dbg = (int)value;
+    } else if (strcmp(key, "qkv_one_launch") == 0) g_qkv_one = (int)value < -1 ? -2 : (int)value;
     else return false;
     return true;
 }
+static void gemm_env_init();
 static void desync_for(GemmArgs& q, long long tiles) {
-    if (g_desync < 0) {
-        const char* e = getenv("ESMK_RESID_DESYNC");
-        g_desync = e ? atof(e) : kDesyncDefault;
-    }
-    if (g_desync_group < 0) {
-        const char* e = getenv("ESMK_RESID_DESYNC_GROUP");
-        g_desync_group = e ? atoi(e) : 0;
-    }
+    gemm_env_init();
     // only launches of at least two rounds of tiles: the delay is paid once, a hidden burst is won per further round
-    if (g_desync > 0 && tiles >= 512) {
-        q.desync = (int)(g_desync * (double)(q.K / 64) * 2700.0);
-        q.desync_group = g_desync_group;
+    const double ds = g_desync.load();
+    if (ds > 0 && tiles >= 512) {
+        q.desync = (int)(ds * (double)(q.K / 64) * 2700.0);
+        q.desync_group = g_desync_group.load();
     }
 }
 
@@ -407,6 +412,15 @@ static void gemm_env_init() {
         if (const char* m = getenv("ESMK_GEMM9_MASK")) g_mask9 = atoi(m);
         if (const char* k = getenv("ESMK_GEMM9_MIN_K")) g_mink9 = atoi(k);
         if (const char* v = getenv("ESMK_GEMM9_VAR")) g_auto_var = atoi(v);  // issue pattern of the auto choice (2 | 3: A/B)
+        if (g_desync.load() < 0) {  // not set through esmk_debug_set
+            const char* e = getenv("ESMK_RESID_DESYNC");
+            g_desync = e ? atof(e) : kDesyncDefault;
+        }
+        if (g_desync_group.load() < 0) {
+            const char* e = getenv("ESMK_RESID_DESYNC_GROUP");
+            g_desync_group = e ? atoi(e) : 0;
+        }
+        if (const char* e = getenv("ESMK_QKV_ONE_LAUNCH")) g_qkv_one_env = atoi(e);
     });
 }
 
@@ -424,20 +438,19 @@ static double gemm9_round_cost(int M, int N) {
 // half-height tiles = two part-filled rounds against one of 120; B = 64: 10 + 5 against 15 rounds — no gain, the two launches stay).  ESMK_QKV_ONE_LAUNCH
 // = 0 / 1 forces the choice (A/B runs); the results are bit-identical either way.
 bool gemm_qkv_one_launch(const GemmArgs& qk) {
-    static const int env = [] { const char* e = getenv("ESMK_QKV_ONE_LAUNCH"); return e ? atoi(e) : -1; }();
     static const bool env_old = [] { const char* e = getenv("ESMK_GEMM"); return e != nullptr && strcmp(e, "old") == 0; }();
     gemm_env_init();
-    const int mode = g_qkv_one >= -1 ? g_qkv_one : env;  // esmk_debug_set("qkv_one_launch", -1 | 0 | 1) overrides the environment
+    const int knob = g_qkv_one.load();
+    const int mode = knob >= -1 ? knob : g_qkv_one_env.load();  // esmk_debug_set("qkv_one_launch", -1 | 0 | 1) overrides the environment
     GemmArgs all = qk;
     all.N = 3 * qk.E;
     if (mode == 0 || qk.N != 2 * qk.E || g_impl == 8 || env_old || qk.force_old || qk.force_generic || qk.dbg ||
         !gemm9_supports(all, EPI_QKV_ALL))
         return false;
     if (mode == 1) return true;
-    // the combined kernel exists with half-height tiles only (the full-height instantiation holding both K loops ran out of
-    // registers: accumulator quads shuffled through VGPRs in the loop, 1.7 x the time per tile)
-    const long long tiles_h = (long long)((qk.M + 127) / 128) * ((3 * qk.E + 255) / 256);
-    return 0.58 * (double)((tiles_h + 255) / 256) < gemm9_round_cost(qk.M, 2 * qk.E) + gemm9_round_cost(qk.M, qk.E) - 0.25;
+    // either tile height (round 5: the full-height instantiation holds both K loops without accumulator traffic since its
+    // quads are pinned to the AGPR file, gemm9.hip) — launch_gemm picks the height of the combined launch by the same rule
+    return gemm9_round_cost(qk.M, 3 * qk.E) < gemm9_round_cost(qk.M, 2 * qk.E) + gemm9_round_cost(qk.M, qk.E) - 0.25;
 }
 
 hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st) {
@@ -476,13 +489,13 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
                 const double wg = 256.0;
                 const double cost_f = (double)((tiles + 255) / 256), cost_h = 0.58 * (double)((tiles_h + 255) / 256);
                 (void)wg;
-                half = p.half_m > 0 || (p.half_m == 0 && cost_h < 0.92 * cost_f) || epi == EPI_QKV_ALL;
+                half = p.half_m > 0 || (p.half_m == 0 && cost_h < 0.92 * cost_f);
                 use9 = true;
             }
             if (use9) {
                 GemmArgs q = p;
                 q.half_m = half ? 1 : 0;
-                q.lnf_dbg = g_lnf_dbg;
+                q.lnf_dbg = g_lnf_dbg.load();
                 if (epi == EPI_RESID_F32 && !half && g_auto_var == 0 && !lnf) desync_for(q, tiles);
                 return launch_gemm9(q, epi, operand_dtype, (half || only9) ? 0 : g_auto_var, st);
             }

@@ -567,7 +567,8 @@ static hipError_t launch8(GemmArgs p, hipStream_t st) {
 
 template <typename T>
 static hipError_t dispatch8(const GemmArgs& p, int epi, hipStream_t st) {
-    if (p.dbg) {  // timing experiments and schedule A/B (tools/microbench.py)
+    if (p.dbg) {  // timing experiments (tools/microbench.py; results wrong): ESMK_EXPERIMENTS builds only
+#ifdef ESMK_EXPERIMENTS
         if constexpr (std::is_same<T, _Float16>::value) {
             if (epi == EPI_STORE_T) {
                 switch (p.dbg) {
@@ -588,6 +589,7 @@ static hipError_t dispatch8(const GemmArgs& p, int epi, hipStream_t st) {
             }
             if (p.dbg == 0x90 && epi == EPI_RESID_F32) return launch8<T, EPI_RESID_F32, 0, 128>(p, st);
         }
+#endif
         return hipErrorInvalidValue;
     }
     // ESMK_GEMM8_MODE (read once): engine-level A/B of kernel variants with bench.py

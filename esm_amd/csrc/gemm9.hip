@@ -118,7 +118,7 @@ ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base,
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int m = m_base + 32 * i + it * 8 + (lane >> 3);
-            cmv[i & 1][it] = (p.lnf_dbg & 4) ? 0.f : p.ln_mean[FULL ? m : min(m, p.M - 1)];
+            cmv[i & 1][it] = (kExperiments && (p.lnf_dbg & 4)) ? 0.f : p.ln_mean[FULL ? m : min(m, p.M - 1)];
         }
     };
     if constexpr (LNF)
@@ -193,7 +193,7 @@ ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base,
                     recv.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xf, 0xf, true);
                     const u32x4 o = odd ? u32x4{recv.x, recv.y, cur.x, cur.y} : u32x4{prev.x, prev.y, recv.x, recv.y};
                     const int col = n_base + (odd ? 32 * jb + 4 * (cc - 1) : 32 * (jb - 1) + 4 * cc);
-                    if ((FULL || (m < p.M && col < p.N)) && !(p.lnf_dbg & 1)) {
+                    if ((FULL || (m < p.M && col < p.N)) && !(kExperiments && (p.lnf_dbg & 1))) {
                         auto* hd = reinterpret_cast<u32x4*>(h16 + (size_t)m * p.ldh + col);
                         if constexpr (NT) __builtin_nontemporal_store(o, hd);
                         else *hd = o;
@@ -204,7 +204,7 @@ ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base,
         if constexpr (EPI == EPI_RESID_F32)
             if (piece + D < NP) load_old(old[piece % D], piece + D);
         if constexpr (LNF) {
-            if (jb == 3 && lnp && !(p.lnf_dbg & 2)) {  // the wave's 128 columns of rows 32 i .. 32 i + 31 are complete
+            if (jb == 3 && lnp && !(kExperiments && (p.lnf_dbg & 2))) {  // the wave's 128 columns of rows 32 i .. 32 i + 31 are complete
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     // the row's eight lanes: lane l adds lanes l-1, then l-2, l-3, then l-4 .. l-7 (DPP row_shr, zeros
@@ -401,7 +401,7 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base, i
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], rs, bs1[e]);
                 }
-                if constexpr (EPI == EPI_GELU_T) gelu_fast_x8(v);  // four chains: one wave per SIMD has no partner to fill VALU gaps
+                if constexpr (EPI == EPI_GELU_T) gelu_fast_x8<true>(v);  // four chains: one wave per SIMD has no partner to fill VALU gaps
                 V8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = Op<T>::from(v[e]);
@@ -971,8 +971,9 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
     if (var == 2) { ESMK_G9_ALL(2) }  // A/B of the issue patterns in the whole forward (ESMK_GEMM_IMPL=9:2 / 9:3)
     if (var == 3) { ESMK_G9_ALL(3) }
 #undef ESMK_G9_ALL
+#ifdef ESMK_EXPERIMENTS
     if constexpr (std::is_same<T, _Float16>::value) {
-        if (p.half_m > 0 && epi == EPI_STORE_T) {  // timing experiments on the half-height kernel
+        if (p.half_m > 0 && epi == EPI_STORE_T) {  // timing experiments on the half-height kernel (results wrong)
             switch (var) {
                 case 8: return launch9<T, EPI_STORE_T, 8, true>(p, st);
                 case 16: return launch9<T, EPI_STORE_T, 16, true>(p, st);
@@ -984,6 +985,7 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
             }
         }
     }
+#endif
     if (gemm9_ln_fold(p, epi)) {  // LayerNorm fold: producer / consumer forms of the four epilogues, both tile heights
         if (var != 0) return hipErrorInvalidValue;
         if (epi == EPI_RESID_F32 && (p.h16 == nullptr || p.ln_mean == nullptr || p.ldh < p.N || p.ln_parts < (p.N + 127) / 128))
@@ -1033,9 +1035,13 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
     }
     if constexpr (std::is_same<T, _Float16>::value) {
         if (epi == EPI_STORE_T) {  // timing experiments (tools/bench_gemm9.py --dbg)
-            switch (var) {
+            switch (var) {  // schedule variants: same results
                 case 1: return launch9<T, EPI_STORE_T, 1>(p, st);
                 case 7: return launch9<T, EPI_STORE_T, 7>(p, st);
+                case 512: return launch9<T, EPI_STORE_T, 512>(p, st);    // K stagger by column block
+                case 2048: return launch9<T, EPI_STORE_T, 2048>(p, st);  // non-temporal operand loads
+                case 4096: return launch9<T, EPI_STORE_T, 4096>(p, st);  // plain (temporal) stores
+#ifdef ESMK_EXPERIMENTS  // parts of the kernel removed: results wrong
                 case 8: return launch9<T, EPI_STORE_T, 8>(p, st);
                 case 16: return launch9<T, EPI_STORE_T, 16>(p, st);
                 case 32: return launch9<T, EPI_STORE_T, 32>(p, st);
@@ -1043,10 +1049,8 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
                 case 128: return launch9<T, EPI_STORE_T, 128>(p, st);
                 case 96: return launch9<T, EPI_STORE_T, 96>(p, st);
                 case 224: return launch9<T, EPI_STORE_T, 224>(p, st);
-                case 512: return launch9<T, EPI_STORE_T, 512>(p, st);    // K stagger by column block
                 case 1040: return launch9<T, EPI_STORE_T, 1040>(p, st);  // no MFMAs, half the DMA bytes
-                case 2048: return launch9<T, EPI_STORE_T, 2048>(p, st);  // non-temporal operand loads
-                case 4096: return launch9<T, EPI_STORE_T, 4096>(p, st);  // plain (temporal) stores
+#endif
             }
         }
     }

@@ -257,7 +257,7 @@ ESMK_DEV void epilogue8m(const GemmArgs& p, f32x4 (&acc)[NJT][NMI], int nj0, int
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[nj0 + nj][2 * i + mi2][e];
-                    if constexpr (EPI == EPI_GELU_T) gelu_fast_x4(v);
+                    if constexpr (EPI == EPI_GELU_T) gelu_fast_x4<true>(v);
                     *reinterpret_cast<V4*>(wl + row * 128 + (((2 * nj + (g4 >> 1)) ^ (row & 7)) << 4) + 8 * (g4 & 1)) =
                         pack4_<T>(v[0], v[1], v[2], v[3]);
                 }

@@ -452,6 +452,13 @@ class ESM2(nn.Module):
         return [dict(name=buf[i].name.decode(), launches=buf[i].launches, ms=buf[i].ms, flops=buf[i].flops,
                      bytes=buf[i].bytes) for i in range(n.value)]
 
+    def ln_fold_active(self):
+        """True / False: the engine of this model runs with / without the LayerNorm fold; None before the
+        first forward."""
+        if self._engine is None:
+            return None
+        return bool(self._engine.N.lib.esmk_ln_fold_enabled(self._engine.handle) == 1)
+
     def refresh_engine(self):
         """Drop the engine state (call after replacing Parameter objects or sub-modules)."""
         if self._engine is not None:

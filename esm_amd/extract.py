@@ -387,10 +387,13 @@ def create_parser():
                    help="accepted for command-line compatibility with scripts/extract.py and refused: the engine has "
                         "no CPU path")
     p.add_argument("--writer_threads", type=int, default=0, help="result-file writer threads (0 = from the host's cores)")
-    p.add_argument("--crc32", action="store_true",
-                   help="let torch.save compute the zip CRC32 of every record (the reference's files carry it; torch.load never "
-                        "checks it).  Default off: the checksum is 1.2 of the 3.3 ms a 5 MB per-token file costs "
-                        "(torch.serialization.set_crc32_options)")
+    p.add_argument("--no_crc32", action="store_true",
+                   help="write the result files WITHOUT the zip CRC32 of their records (torch.serialization.set_crc32_options): "
+                        "torch.load never checks it, and the checksum is 1.2 of the 3.3 ms a 5 MB per-token file costs (+ 6 %% "
+                        "per-token extraction at 8 ranks per host), but zipfile / unzip -t and archive tooling report such files "
+                        "as corrupt.  Default: files like the reference's scripts/extract.py writes them, checksum included; "
+                        "ESM_AMD_EXTRACT_NO_CRC32=1 is the same switch")
+    p.add_argument("--crc32", action="store_true", help=argparse.SUPPRESS)  # round-4 spelling of the (now default) behaviour
     p.add_argument("--no_varlen", action="store_true",
                    help="always run padded batches (default: token-packed batches whenever they save >= 8 %% of the rows)")
     p.add_argument("--mean_matrix", type=pathlib.Path, default=None,
@@ -416,8 +419,9 @@ def main(argv=None):
     dist, rank, world, local_rank = init_ranks(world_env, "nccl")  # nccl == RCCL on ROCm
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if not args.crc32 and hasattr(torch.serialization, "set_crc32_options"):
-        torch.serialization.set_crc32_options(False)  # process wide: this process only writes result files
+    no_crc = (args.no_crc32 or os.environ.get("ESM_AMD_EXTRACT_NO_CRC32", "0") == "1") and not args.crc32
+    if no_crc and hasattr(torch.serialization, "set_crc32_options"):
+        torch.serialization.set_crc32_options(False)  # opt-in, process wide: this process only writes result files
     model, alphabet = pretrained.load_model_and_alphabet(args.model_location)
     if isinstance(model, MSATransformer):  # scripts/extract.py:66-69
         raise ValueError("This script currently does not handle models with MSA input (MSA Transformer).")

@@ -65,15 +65,18 @@ def pin_rank_cpus(local_rank: int, local_world: int, force: bool = False):
     """Restrict this process (and the threads it starts) to its share of the host's CPUs.  ``ESM_AMD_NO_AFFINITY=1``
     switches it off.  Returns the CPU set in effect.
 
-    Only a process that still sees the WHOLE host is sliced: when the launcher (torchrun NUMA binding, taskset, a cgroup per
-    rank) already gave this rank a CPU set of its own, that set is kept as it is — slicing it again would leave e.g. 2 of 16
-    CPUs to the tokeniser, the writer threads and the GPU driver thread.  ``force`` slices regardless (the host
-    benchmark, which starts its ranks itself from one unrestricted parent)."""
+    A CPU set that already looks PER-RANK is kept as it is: when the launcher (torchrun NUMA binding, taskset, a cgroup
+    per rank) gave this rank at most a 1 / local_world share of the host, slicing it again would leave e.g. 2 of 16 CPUs
+    to the tokeniser, the writer threads and the GPU driver thread.  A restricted set that is still LARGER than
+    one rank's share is a set all ranks of the job share (docker --cpuset-cpus, a Slurm job cpuset): every rank sees the
+    same CPUs, so it is sliced like the whole host would be — otherwise 8 ranks' threads contend on the shared CPUs
+    (ADVICE r4).  ``force`` slices regardless."""
     if os.environ.get("ESM_AMD_NO_AFFINITY", "0") == "1" or not hasattr(os, "sched_setaffinity"):
         return set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set()
     have = os.sched_getaffinity(0)
-    if not force and len(have) < (os.cpu_count() or len(have)):
-        return set(have)  # restricted by whoever started us: not ours to narrow further
+    host = os.cpu_count() or len(have)
+    if not force and local_world > 1 and len(have) <= host // local_world:
+        return set(have)  # a per-rank set from whoever started us: not ours to narrow further
     want = rank_cpu_slice(local_rank, local_world)
     try:
         os.sched_setaffinity(0, want)

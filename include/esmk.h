@@ -77,7 +77,10 @@ typedef struct esmk_config {
      * operand-dtype rows and their statistics, and the standalone per-layer LayerNorm passes disappear (plain fp16 / bf16
      * operands, head_dim <= 64; esmk_create fails otherwise); -1 = off; 0 = the library's default (environment
      * ESMK_LN_FOLD=0|1 overrides it).  With the fold the LayerNorm weight and bias of a layer MUST be packed before
-     * that layer's q/k/v and fc1 weights (esmk_pack_weight fails otherwise; esmk_forward fails while a fold is stale). */
+     * that layer's q/k/v and fc1 weights (esmk_pack_weight fails otherwise; esmk_forward fails while a fold is stale).
+     * The handle tracks the fold of ONE packed image at a time — the one esmk_pack_weight last wrote to; packing into a
+     * different image starts from "nothing packed", and esmk_forward refuses an image the handle did not pack.
+     * Library default since round 5: ON. */
     int32_t ln_fold;
 } esmk_config;
 
@@ -192,6 +195,9 @@ typedef struct esmk_profile_entry {
 } esmk_profile_entry;
 int esmk_profile_begin(esmk_model* m);
 int esmk_profile_end(esmk_model* m, esmk_profile_entry* out, int max_entries, int* n_out);
+/* 1 if the handle runs with the LayerNorm fold (esmk_config::ln_fold resolved against the library default and
+ * ESMK_LN_FOLD), 0 if not, -1 for a null / MSA handle.  Measurement scripts record the mode next to their numbers. */
+int esmk_ln_fold_enabled(const esmk_model* m);
 
 /* ---- single-kernel entry points (used by the parity tests and micro-benchmarks) -------- */
 
@@ -251,7 +257,9 @@ int esmk_debug_mma_selftest(const void* a_dev, const void* b_dev, const float* c
 int esmk_debug_gemm_impl(int impl, int variant);
 
 /* Measurement / A-B hook (no reference counterpart): named tuning knobs of the library, process wide.  Timing only —
- * no knob changes a result bit.  "resid_desync" (>= 0): start-up delay of every other XCD's workgroups in the residual
+ * no knob changes a result bit.  (Timing experiments that DO break results — kernels with their MFMAs, exponentials,
+ * DMA or epilogue stores removed: the "lnf_dbg" knob, ESMK_ATTN_HACK, the gemm8 / gemm9 variant codes with parts switched
+ * off — exist only in libraries built with ESMK_HIPCC_EXTRA="-DESMK_EXPERIMENTS"; the shipped library refuses them.)  "resid_desync" (>= 0): start-up delay of every other XCD's workgroups in the residual
  * GEMMs (out-projection, fc2), as a fraction of one tile's main loop, which takes the HBM-bound read-modify-write
  * epilogues of the two halves of the chip out of lockstep (gemm9.hip; environment: ESMK_RESID_DESYNC);
  * "resid_desync_group": 0 = odd XCDs late, 1 = every other workgroup of each XCD, 2 = four phases.

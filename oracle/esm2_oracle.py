@@ -16,7 +16,8 @@ It works on a state dict (reference key names) — it does not use esm_amd's mod
 ``inject`` (default None: nothing is touched, the fp32 reference computation): ``(kinds, dtype)`` rounds the named
 operand groups to a 16-bit dtype and back before they enter a contraction — "W" linear-layer weights, "A" linear-layer
 inputs, "QK" rotated q / k, "V" values, "P" softmax probabilities ("MAPX": the returned attention maps come from the
-unrounded q / k — study hook for a split-q contact sweep; ``inject_head``: the LM head's own setting).  With all five it is the accuracy FLOOR of any engine
+unrounded q / k — study hook for a split-q contact sweep; "A!qk": group A is not rounded at the q / k projections (sites qk,
+v, o, fc1, fc2); "W8": weights as fp16 + a block-scaled fp8 remainder; ``inject_head``: the LM head's own setting).  With all five it is the accuracy FLOOR of any engine
 that feeds 16-bit operands to fp32-accumulating matrix cores; tools/esm2_precision_study.py and the parity tests
 read the HIP engine's error against it.
 """
@@ -29,12 +30,33 @@ import torch.nn.functional as F
 ALL_OPERANDS = ("W", "A", "QK", "V", "P")
 
 
-def _rnd(t, inject, kind):
-    return t if inject is None or kind not in inject[0] else t.to(inject[1]).float()
+def _rnd(t, inject, kind, site=None):
+    # "A!qk" in the kinds: group A is NOT rounded at site "qk" (study hook: which sites need wider operands)
+    if inject is None or kind not in inject[0] or (site is not None and f"{kind}!{site}" in inject[0]):
+        return t
+    return t.to(inject[1]).float()
 
 
-def _linear(x, w, b, inject):
-    return F.linear(_rnd(x, inject, "A"), _rnd(w, inject, "W"), b)
+def _mx8(t):
+    """Block-scaled fp8 (e4m3, one power-of-two scale per 32 elements of the contraction axis): the operand format of
+    v_mfma_scale_f32_16x16x128_f8f6f4 — study hook only (tools/contract_mode_study.py)."""
+    shp = t.shape
+    K = shp[-1]
+    pad = (-K) % 32
+    u = F.pad(t, (0, pad)).reshape(*shp[:-1], -1, 32)
+    e = torch.floor(torch.log2(u.abs().amax(-1, keepdim=True).clamp_min(1e-38)))
+    scale = torch.exp2(e - 7)  # the block maximum lands in [128, 256): inside e4m3's range (448), 3 mantissa bits
+    q = (u / scale).to(torch.float8_e4m3fn).float() * scale
+    return q.reshape(*shp[:-1], -1)[..., :K]
+
+
+def _linear(x, w, b, inject, site=None):
+    if inject is not None and "W8" in inject[0]:
+        # study hook: W = fp16(W) + mx8(W - fp16(W)); the lo product takes block-scaled fp8 activations as well
+        hi = w.to(torch.float16).float()
+        xa = _rnd(x, inject, "A", site)
+        return F.linear(xa, hi, b) + F.linear(_mx8(x), _mx8(w - hi))
+    return F.linear(_rnd(x, inject, "A", site), _rnd(w, inject, "W", site), b)
 
 
 def gelu(x):
@@ -72,9 +94,9 @@ def attention_layer(sd, prefix, x, heads, pad_mask, need_weights, use_rope=True,
     B, T, E = x.shape
     d = E // heads
     p = prefix + "self_attn."
-    q = _linear(x, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"], inject) * (d ** -0.5)
-    k = _linear(x, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"], inject)
-    v = _linear(x, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"], inject)
+    q = _linear(x, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"], inject, "qk") * (d ** -0.5)
+    k = _linear(x, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"], inject, "qk")
+    v = _linear(x, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"], inject, "v")
     q, k, v = (t.view(B, T, heads, d).transpose(1, 2) for t in (q, k, v))  # [B,H,T,d]
     if use_rope:  # ESM-2 (TransformerLayer(use_rotary_embeddings=True), esm2.py:57-66); ESM-1b has none
         cos, sin = rope_tables(T, d, x.device)
@@ -93,7 +115,7 @@ def attention_layer(sd, prefix, x, heads, pad_mask, need_weights, use_rope=True,
             sx = sx.masked_fill(pad_mask[:, None, None, :], float("-inf"))
         maps = torch.softmax(sx.float(), dim=-1)
     ctx = (_rnd(probs, inject, "P") @ _rnd(v, inject, "V")).transpose(1, 2).reshape(B, T, E)
-    out = _linear(ctx, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"], inject)
+    out = _linear(ctx, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"], inject, "o")
     return out, (maps if need_weights else None)
 
 
@@ -104,8 +126,8 @@ def transformer_layer(sd, i, x, heads, pad_mask, need_weights, use_rope=True, in
     a, probs = attention_layer(sd, p, h, heads, pad_mask, need_weights, use_rope, inject)
     x = x + a
     h = layer_norm(x, sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"])
-    h = gelu(_linear(h, sd[p + "fc1.weight"], sd[p + "fc1.bias"], inject))
-    h = _linear(h, sd[p + "fc2.weight"], sd[p + "fc2.bias"], inject)
+    h = gelu(_linear(h, sd[p + "fc1.weight"], sd[p + "fc1.bias"], inject, "fc1"))
+    h = _linear(h, sd[p + "fc2.weight"], sd[p + "fc2.bias"], inject, "fc2")
     return x + h, probs
 
 

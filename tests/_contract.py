@@ -1,0 +1,80 @@
+"""The parity contract of the engine — ONE definition, used by every `-m gpu` parity test and quoted in DESIGN.md §2.
+
+North star: "outputs within 1e-3 rel of the CPU reference", rel = max|diff| / max|ref| over non-pad positions.
+An engine that feeds 11-bit (fp16) operands to fp32-accumulating matrix cores has an accuracy FLOOR that no kernel work
+moves: the fp32 oracle with every MFMA operand (weights, GEMM inputs, q / k, v, P) rounded to fp16 (`oracle.esm2_oracle`
+`inject`).  On a 33 - 36-layer stack that floor is 8.6 - 9.6e-4 in L2 and 0.83 - 1.18e-3 in the max norm for the
+representations (the max of 10^6 - 10^8 noisy elements scatters +-15 % with the seed and re-rolls with any change of
+rounding pattern) and 1.1 - 1.6e-3 for logits / contact logits (profiles/r2_esm2_precision_floor_*.log,
+r4_parity_budget_study.log).  Hence:
+
+  representations (the BASELINE metric's output):  rel L2 <= 1e-3, HARD, on every deep (>= 30-layer) configuration;
+                                                   rel max <= max(1e-3, SLACK x floor_max on the SAME inputs)
+  logits, contact logits, few-layer toy models:    both norms <= max(1e-3, SLACK x the floor's on the same inputs)
+                                                   (plain fp16 operands do NOT reach 1e-3 there and the tests say so;
+                                                   ESM_AMD_OPERAND=f16x2 does for representations and logits)
+
+SLACK = 1.25: two realisations of "the maximum of the same noise over the tensor" (engine vs emulation: different
+summation orders, fused vs separate roundings) differ by up to ~15 % on the committed fixtures; a real defect — one
+un-normalised row, a missed mask, a wrong rounding point — shows as 2 x or more, and in L2.
+Integer outputs (tokens, argmax wherever the reference's top-2 margin exceeds twice the logit error) are exact.
+"""
+import json
+import os
+
+import torch
+
+CONTRACT = 1e-3
+SLACK = 1.25
+_FLOORS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "operand_floors.json")
+
+
+def errors(got, ref, mask=None):
+    """(rel L2, rel max) of got against ref over `mask`."""
+    if mask is not None:
+        got, ref = got[mask], ref[mask]
+    got, ref = got.double().cpu(), ref.double().cpu()
+    d = got - ref
+    return (d.norm() / ref.norm().clamp_min(1e-30)).item(), (d.abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def floor_forward(sd, toks, L, H, dtype=torch.float16, **kw):
+    """The oracle with `dtype` rounding injected at every MFMA operand: the floor on these inputs."""
+    from oracle.esm2_oracle import ALL_OPERANDS, esm2_forward
+
+    return esm2_forward(sd, toks, L, H, inject=(frozenset(ALL_OPERANDS), dtype), **kw)
+
+
+def committed_floor(case, seq=0):
+    """Floor numbers of a full-size fixture (tests/golden/make_floors.py -> operand_floors.json)."""
+    with open(_FLOORS) as f:
+        return json.load(f)[case][seq]
+
+
+def check(name, l2, mx, floor_l2, floor_mx, hard_l2=False, slack=SLACK):
+    """Assert the contract on measured (l2, mx) given the floor's numbers on the same inputs; prints one line that the
+    evidence scripts grep ("contract ...")."""
+    b_l2 = CONTRACT if hard_l2 else max(CONTRACT, slack * floor_l2)
+    b_mx = max(CONTRACT, slack * floor_mx)
+    print(f"contract {name}: L2 {l2:.2e} (floor {floor_l2:.2e}, bound {b_l2:.2e}{' hard' if hard_l2 else ''}), "
+          f"max {mx:.2e} (floor {floor_mx:.2e}, x{mx / max(floor_mx, 1e-30):.2f}, bound {b_mx:.2e})")
+    assert l2 <= b_l2, (name, "L2", l2, b_l2)
+    assert mx <= b_mx, (name, "max norm", mx, b_mx, floor_mx)
+    return l2, mx
+
+
+def check_tensors(name, got, ref, floor, mask=None, hard_l2=False, slack=SLACK):
+    l2, mx = errors(got, ref, mask)
+    f_l2, f_mx = errors(floor, ref, mask)
+    return check(name, l2, mx, f_l2, f_mx, hard_l2=hard_l2, slack=slack)
+
+
+def contact_logit_errors(c, cr, sat=12.0):
+    """(max logit error, that error relative to the largest unsaturated reference logit) of contact probabilities."""
+    lg = lambda t: torch.logit(t.double().cpu().clamp(1e-12, 1 - 1e-12))
+    z, zr = lg(c), lg(cr)
+    ok = zr.abs() < sat
+    if not bool(ok.any()):
+        return 0.0, 0.0
+    e = (z - zr)[ok].abs().max().item()
+    return e, e / zr[ok].abs().max().item()

@@ -135,8 +135,10 @@ def test_secondary_workloads_glue(monkeypatch):
     import time as _t
 
     out = bench.secondary_workloads(extra=["--protocol-test"], budget_end=_t.perf_counter() + 1000)
-    assert list(out) == ["msa1b", "extract_650m", "esm2_3b_contacts", "esm2_650m_b4", "esm2_650m_b4_ln_fold"]
-    assert out["esm2_650m_b4_ln_fold"]["config"]["ln_fold"] == "1" and out["esm2_650m_b4"]["config"]["ln_fold"] != "1"
+    assert list(out) == ["msa1b", "extract_650m", "esm2_3b_contacts", "esm2_650m_plain", "esm2_650m_b4", "esm2_650m_b4_plain"]
+    # the plain lines switch the LayerNorm fold off, the others leave the library default (on since round 5)
+    assert out["esm2_650m_b4_plain"]["config"]["ln_fold"] == "0" and out["esm2_650m_plain"]["config"]["ln_fold"] == "0"
+    assert out["esm2_650m_b4"]["config"]["ln_fold"] != "0"
     for name, r in out.items():
         assert "error" not in r, (name, r)
         assert r["metric"].startswith("protocol-test") and r["ms_per_step"] >= 4.5 and r["wall_s"] > 0
@@ -191,29 +193,50 @@ def test_skip_param_init_then_strict_load_gives_the_state_dict():
 
 
 def test_pmc_traffic_is_gated_by_the_library_hash(tmp_path, monkeypatch):
-    """roofline.traffic comes from the committed PMC summary only for the library it profiled — or for one the committed
-    ISA comparison names as identical in every kernel the workloads launch, and then the source string says so."""
+    """roofline.traffic comes from a committed PMC summary only when that summary was taken on exactly this (workload,
+    per-GPU batch, LayerNorm-fold mode) AND on the library that is running; anything else is null with the reason
+    (VERDICT r4 Weak-6: the B = 4 lines used to report the B = 64 launch's bytes)."""
     sys.path.insert(0, ROOT)
     import bench
 
-    summ = tmp_path / "pmc.json"
-    summ.write_text(json.dumps({"library_src_hash": "aaaa", "git_sha": None,
-                                "kernels": {"gemm_fc1_gelu": {"hbm_bytes_corrected": 123.0}}}))
-    eq = tmp_path / "eq.json"
-    eq.write_text(json.dumps({"aaaa": {"bbbb": {"evidence": "profiles/x.txt", "differs_in": "kernel K"}}}))
-    monkeypatch.setitem(bench.PMC_SUMMARY, "esm2_650m", str(summ))
-    monkeypatch.setattr(bench, "ISA_EQUIVALENCE", str(eq))
-    v, src = bench.pmc_traffic("gemm_fc1_gelu", "aaaa")
-    assert v == 123.0 and "aaaa" in src and "differs" not in src
-    v, src = bench.pmc_traffic("gemm_fc1_gelu", "bbbb")
-    assert v == 123.0 and "aaaa" in src and "bbbb" in src and "kernel K" in src and "profiles/x.txt" in src
-    v, src = bench.pmc_traffic("gemm_fc1_gelu", "cccc")
+    monkeypatch.setattr(bench, "PMC_DIR", str(tmp_path))
+
+    def write(workload, batch, fold, h, val):
+        with open(bench.pmc_summary_path(workload, batch, fold), "w") as f:
+            json.dump({"library_src_hash": h, "git_sha": "deadbeef", "workload": workload, "batch": batch, "ln_fold": fold,
+                       "kernels": {"gemm_fc1_gelu": {"hbm_bytes_corrected": val}}}, f)
+
+    write("esm2_650m", 64, True, "aaaa", 123.0)
+    v, src = bench.pmc_traffic("gemm_fc1_gelu", "aaaa", "esm2_650m", 64, True)
+    assert v == 123.0 and "aaaa" in src and "batch 64" in src and "deadbeef" in src
+    assert bench.pmc_traffic("gemm_fc1_gelu", "aaaa", "esm2_650m", None, True)[0] == 123.0   # None = the workload's default batch
+    # another library
+    v, src = bench.pmc_traffic("gemm_fc1_gelu", "cccc", "esm2_650m", 64, True)
     assert v is None and "aaaa" in src and "cccc" in src
-    monkeypatch.setattr(bench, "ISA_EQUIVALENCE", str(tmp_path / "missing.json"))
-    assert bench.pmc_traffic("gemm_fc1_gelu", "bbbb")[0] is None
-    # the committed files: the equivalence table only names hashes whose evidence file exists
-    with open(os.path.join(ROOT, "profiles", "r4_isa_equivalence.json")) as f:
-        for profiled, others in json.load(f).items():
-            for h, e in others.items():
-                assert os.path.exists(os.path.join(ROOT, e["evidence"])), e
-                assert h in open(os.path.join(ROOT, e["evidence"])).read() and profiled in open(os.path.join(ROOT, e["evidence"])).read()
+    # another batch / another fold mode: their own files, which do not exist -> null, never the B = 64 fold figure
+    v, src = bench.pmc_traffic("gemm_fc1_gelu", "aaaa", "esm2_650m", 4, True)
+    assert v is None and "missing" in src and "_b4" in src
+    v, src = bench.pmc_traffic("gemm_fc1_gelu", "aaaa", "esm2_650m", 64, False)
+    assert v is None and "_plain" in src
+    v, src = bench.pmc_traffic("gemm_fc1_gelu", "aaaa", "esm2_650m", 4, False)
+    assert v is None and "_b4_plain" in src
+    # their own summaries are picked up, each for its own key only
+    write("esm2_650m", 4, True, "aaaa", 7.0)
+    write("esm2_650m", 4, False, "aaaa", 9.0)
+    assert bench.pmc_traffic("gemm_fc1_gelu", "aaaa", "esm2_650m", 4, True)[0] == 7.0
+    assert bench.pmc_traffic("gemm_fc1_gelu", "aaaa", "esm2_650m", 4, False)[0] == 9.0
+    assert bench.pmc_traffic("gemm_fc1_gelu", "aaaa", "esm2_650m", 64, True)[0] == 123.0
+    # a summary whose recorded key contradicts its file name is refused
+    with open(bench.pmc_summary_path("esm2_650m", 8, True), "w") as f:
+        json.dump({"library_src_hash": "aaaa", "workload": "esm2_650m", "batch": 64, "ln_fold": True,
+                   "kernels": {"gemm_fc1_gelu": {"hbm_bytes_corrected": 1.0}}}, f)
+    assert bench.pmc_traffic("gemm_fc1_gelu", "aaaa", "esm2_650m", 8, True)[0] is None
+    # a class the summary does not hold
+    assert bench.pmc_traffic("attention", "aaaa", "esm2_650m", 64, True)[0] is None
+    # the committed summaries of this round describe themselves consistently
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "profiles", f"{bench.PMC_ROUND}_pmc_summary_*.json")):
+        with open(path) as f:
+            sm = json.load(f)
+        assert path == os.path.join(ROOT, "profiles", os.path.basename(bench.pmc_summary_path(sm["workload"], sm["batch"], sm["ln_fold"]))), path
+        assert sm.get("library_src_hash") and sm.get("kernels")

@@ -37,6 +37,8 @@ def test_esm1b_engine_matches_reference_fixture(path):
     with torch.no_grad():
         out = model(fix["tokens"].cuda(), repr_layers=list(range(d["L"] + 1)), return_contacts=True)
     nonpad = fix["tokens"].ne(1)
+    # 2 - 3-layer toy models; the ESM-1b oracle has no rounding-injection hook, so the floor-referenced contract of
+    # tests/_contract.py is applied with the floor measured on ESM-2 toys of the same depth (1.1 - 1.6e-3): 1.25 x = 2e-3
     for layer, ref in fix["representations"].items():
         assert rel_err(out["representations"][layer].cpu(), ref, nonpad) < 2e-3, layer
     assert rel_err(out["logits"].cpu(), fix["logits"], nonpad) < 2e-3

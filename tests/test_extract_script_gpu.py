@@ -16,6 +16,8 @@ from esm_amd import Alphabet
 from esm_amd.synth import synth_esm2_state_dict, write_esm2_checkpoint
 from oracle.esm2_oracle import esm2_forward
 
+import _contract as C
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SCRIPT = "/root/reference/scripts/extract.py"
@@ -48,6 +50,7 @@ def test_reference_extract_call_sequence_on_the_engine(tmp_path, trunc, tpb):
         n = min(trunc, len(s))
         _, _, toks = conv([(label, s)])
         ref = esm2_forward(sd, toks, L, H, repr_layers=[0, 3, 6], return_contacts=True)
+        floor = C.floor_forward(sd, toks, L, H, repr_layers=[3, 6])
         assert got["label"] == label and sorted(got["representations"]) == [0, 3, 6]
         for l in (0, 3, 6):
             full = ref["representations"][l][0]
@@ -56,9 +59,14 @@ def test_reference_extract_call_sequence_on_the_engine(tmp_path, trunc, tpb):
             scale = full.abs().max().item()
             e = (rep - full[1 : n + 1]).abs().max().item() / scale
             worst = max(worst, e)
-            assert e < 2e-3, (label, l, e)
-            assert (got["mean_representations"][l] - full[1 : n + 1].mean(0)).abs().max().item() < 2e-3 * scale
-            assert (got["bos_representations"][l] - full[0]).abs().max().item() < 2e-3 * scale
+            if l == 0:
+                assert e < 1e-6, (label, e)
+                bound = 1e-6
+            else:  # the parity contract (tests/_contract.py): a 6-layer toy model, floor-referenced in both norms
+                _, mx = C.check_tensors(f"extract {label} repr[{l}]", rep, full[1 : n + 1], floor["representations"][l][0, 1 : n + 1])
+                bound = max(C.CONTRACT, C.SLACK * C.errors(floor["representations"][l][0], full)[1])
+            assert (got["mean_representations"][l] - full[1 : n + 1].mean(0)).abs().max().item() <= bound * scale
+            assert (got["bos_representations"][l] - full[0]).abs().max().item() <= bound * scale
         assert got["contacts"].shape == (n, n)
         assert (got["contacts"] - ref["contacts"][0, :n, :n]).abs().max().item() < 8e-3, label
     print(f"reference extract call sequence on the engine ({os.path.basename(script)}): worst representation error {worst:.2e}")

@@ -134,6 +134,34 @@ def test_rank_cpu_slices_partition_the_host():
             assert all(s == set(range(n)) for s in slices)  # too few CPUs to split: everyone keeps all
 
 
+def test_pin_rank_cpus_slices_a_shared_set_and_keeps_a_per_rank_set(monkeypatch):
+    """a cpuset shared by all ranks of a job (larger than one rank's share of the host) is sliced per rank; a
+    set that already is at most one rank's share is kept; ESM_AMD_NO_AFFINITY switches everything off."""
+    import os
+
+    from esm_amd import launch
+
+    state = {"aff": set(range(64))}
+    monkeypatch.setattr(os, "cpu_count", lambda: 256)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(state["aff"]))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: state.__setitem__("aff", set(cpus)))
+    monkeypatch.delenv("ESM_AMD_NO_AFFINITY", raising=False)
+    # 64 of 256 CPUs for a job of 8 ranks: shared (> 256 / 8) -> rank 3 gets its eighth of the 64
+    got = launch.pin_rank_cpus(3, 8)
+    assert len(got) == 8 and got <= set(range(64)) and got == launch.rank_cpu_slice(3, 8, range(64))
+    # 32 CPUs = exactly one rank's share of the host: a per-rank set, kept
+    state["aff"] = set(range(32, 64))
+    assert launch.pin_rank_cpus(3, 8) == set(range(32, 64))
+    # ... unless forced (the host benchmark starts its ranks from one unrestricted parent)
+    assert len(launch.pin_rank_cpus(3, 8, force=True)) == 4
+    # the whole host
+    state["aff"] = set(range(256))
+    assert len(launch.pin_rank_cpus(0, 8)) == 32
+    state["aff"] = set(range(256))
+    monkeypatch.setenv("ESM_AMD_NO_AFFINITY", "1")
+    assert launch.pin_rank_cpus(0, 8) == set(range(256))
+
+
 def test_writer_runs_a_batch_on_all_threads():
     """a batch is several chunk jobs, so more than `depth` threads can work at once and `done` runs once."""
     import threading

@@ -12,6 +12,8 @@ from esm_amd.packing import pack_plan
 from esm_amd.synth import synth_esm2_state_dict
 from oracle.esm2_oracle import esm2_forward
 
+import _contract as C
+
 pytestmark = pytest.mark.gpu
 PAD, MASK, CLS, EOS = 1, 32, 0, 2
 
@@ -76,8 +78,9 @@ def test_packed_against_oracle_and_padded_engine():
         pk = model.forward_varlen(toks, repr_layers=[L], min_saving=None)
         pd = model(toks.cuda(), repr_layers=[L])
     nonpad = toks.ne(PAD)
-    assert rel_err(pk["representations"][L].cpu()[nonpad], ref["representations"][L][nonpad]) < 2e-3
-    assert rel_err(pk["logits"].cpu()[nonpad], ref["logits"][nonpad]) < 2e-3
+    floor = C.floor_forward(sd, toks, L, H, repr_layers=[L])  # the parity contract (tests/_contract.py), toy model
+    C.check_tensors("packed repr", pk["representations"][L].cpu(), ref["representations"][L], floor["representations"][L], nonpad)
+    C.check_tensors("packed logits", pk["logits"].cpu(), ref["logits"], floor["logits"], nonpad)
     # the padded engine computes the same rows (plus the pad rows)
     m = nonpad.cuda()
     assert torch.equal(pk["representations"][L][m], pd["representations"][L][m])

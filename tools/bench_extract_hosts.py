@@ -34,9 +34,9 @@ def _worker(rank, world, port, args, out_dir, q):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    if not getattr(args, "crc32", False) and hasattr(torch.serialization, "set_crc32_options"):
+    if getattr(args, "no_crc32", False) and hasattr(torch.serialization, "set_crc32_options"):
         torch.serialization.set_crc32_options(False)
-    cpus = pin_rank_cpus(rank, world) if not args.no_affinity else set()
+    cpus = pin_rank_cpus(rank, world, force=True) if not args.no_affinity else set()
     torch.set_num_threads(max(1, min(8, len(cpus) or 8)))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -98,7 +98,7 @@ def run(args):
             "files_per_s_per_rank": [round(r[3] / r[1], 1) for r in rows],
             "residues_per_s_total": round(n_files * args.len / wall, 1),
             "file_MB": round(args.len * args.embed_dim * 4 / 1e6, 2) if "per_tok" in args.include else 0.0,
-            "gpu_ms_per_batch": args.gpu_ms, "include": args.include, "crc32": bool(getattr(args, "crc32", False)), "writer_threads": args.writer_threads,
+            "gpu_ms_per_batch": args.gpu_ms, "include": args.include, "crc32": not bool(getattr(args, "no_crc32", False)), "writer_threads": args.writer_threads,
             "gpu_bound_residues_per_s_total": round(args.world * args.toks_per_batch / (args.gpu_ms / 1e3), 1) if args.gpu_ms else None,
         }
         return res
@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--include", nargs="+", default=["mean", "per_tok"])
     ap.add_argument("--out-root", default="/dev/shm" if os.path.isdir("/dev/shm") else None)
     ap.add_argument("--no-affinity", action="store_true")
-    ap.add_argument("--crc32", action="store_true", help="torch.save with the zip CRC32 (the driver's default is without)")
+    ap.add_argument("--no_crc32", action="store_true", help="torch.save without the zip CRC32 (the driver's --no_crc32; its default keeps the checksum)")
     ap.add_argument("--check", action="store_true")
     args = ap.parse_args()
     print(json.dumps(run(args)), flush=True)

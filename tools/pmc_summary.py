@@ -4,8 +4,8 @@
 
 FETCH_SIZE / WRITE_SIZE are KiB per launch; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream
 (MI355X_MICROARCH.md, HBM section), so hbm_bytes_corrected = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  The summary
-records the source hash of the profiled libesmk.so and the git SHA; bench.py reports `roofline.traffic` only when
-the hash matches the library it is running (no stale constants)."""
+records the source hash of the profiled libesmk.so, the git SHA, the per-GPU batch and the LayerNorm-fold mode of the
+profiled run; bench.py reports `roofline.traffic` only when all of them match the run it is describing."""
 import json
 import os
 import re
@@ -34,14 +34,15 @@ def classify(name, nth_epi4):
             # one kernel family for both: out_proj and fc2 alternate in launch order inside every layer
             return "gemm_out_proj" if nth_epi4 % 2 == 0 else "gemm_fc2"
         return EPI_CLASS.get(epi, "gemm_epi" + epi)
-    for key, cls in (("attn_fwd", "attention"), ("layernorm_kernel", "layernorm"), ("attn_probs", "attention_probs"),
+    for key, cls in (("attn_fwd", "attention"), ("layernorm_kernel", "layernorm"), ("ln_finalize", "ln_finalize"),
+                     ("rowstats_kernel", "rowstats"), ("attn_probs", "attention_probs"),
                      ("msa_row_softmax", "msa_row_softmax"), ("contact_", "contacts"), ("embed_kernel", "embed")):
         if key in name:
             return cls
     return None
 
 
-def main(out_path, dbs, workload="esm2_650m"):
+def main(out_path, dbs, workload="esm2_650m", batch=None, ln_fold=None):
     acc = defaultdict(lambda: defaultdict(list))
     for path in dbs:
         c = sqlite3.connect(path)
@@ -94,16 +95,24 @@ def main(out_path, dbs, workload="esm2_650m"):
     json.dump({"source": "tools/profile_bench.sh on MI355X (bench.py --steps 2 --warmup 1 --no-cpu-baseline; one rocprofv3 "
                          "--pmc pass per counter group)",
                "note": "hbm_bytes_corrected = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch (gfx950 FETCH_SIZE correction)",
-               "workload": workload, "library_src_hash": library_hash(), "git_sha": sha, "kernels": kernels},
+               "workload": workload, "batch": batch, "ln_fold": ln_fold, "library_src_hash": library_hash(), "git_sha": sha,
+               "kernels": kernels},
               open(out_path, "w"), indent=1)
     print(json.dumps(kernels, indent=1))
 
 
 if __name__ == "__main__":
     argv = sys.argv[1:]
-    wl = "esm2_650m"
-    if "--workload" in argv:
-        i = argv.index("--workload")
-        wl = argv[i + 1]
-        del argv[i:i + 2]
-    main(argv[0], argv[1:], wl)
+
+    def opt(name, default=None):
+        if name in argv:
+            i = argv.index(name)
+            v = argv[i + 1]
+            del argv[i:i + 2]
+            return v
+        return default
+
+    wl = opt("--workload", "esm2_650m")
+    batch = opt("--batch")        # per-GPU batch of the profiled run and its LayerNorm-fold mode: bench.py reports a traffic
+    fold = opt("--ln-fold")       # figure only for exactly the (workload, batch, mode, library) a summary was taken on
+    main(argv[0], argv[1:], wl, int(batch) if batch is not None else None, None if fold is None else bool(int(fold)))
