@@ -448,9 +448,12 @@ bool gemm_qkv_one_launch(const GemmArgs& qk) {
         !gemm9_supports(all, EPI_QKV_ALL))
         return false;
     if (mode == 1) return true;
-    // either tile height (round 5: the full-height instantiation holds both K loops without accumulator traffic since its
-    // quads are pinned to the AGPR file, gemm9.hip) — launch_gemm picks the height of the combined launch by the same rule
-    return gemm9_round_cost(qk.M, 3 * qk.E) < gemm9_round_cost(qk.M, 2 * qk.E) + gemm9_round_cost(qk.M, qk.E) - 0.25;
+    // The combined kernel exists with HALF-height tiles only.  A full-height instantiation holding both K loops was built
+    // twice: round 4 (accumulator quads shuffled through VGPRs: 1.7 x the time per tile) and round 5 with the quads pinned
+    // to the AGPR file — clean K loops in the ISA report, but on the GPU 26.1 against 20.4 ms per step for q / k / v at
+    // B = 64 and 7.12 against 6.25 ms at B = 16 (profiles/r5_qkv_one_launch_full_height.log): removed again.
+    const long long tiles_h = (long long)((qk.M + 127) / 128) * ((3 * qk.E + 255) / 256);
+    return 0.58 * (double)((tiles_h + 255) / 256) < gemm9_round_cost(qk.M, 2 * qk.E) + gemm9_round_cost(qk.M, qk.E) - 0.25;
 }
 
 hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_t st) {
@@ -489,7 +492,7 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
                 const double wg = 256.0;
                 const double cost_f = (double)((tiles + 255) / 256), cost_h = 0.58 * (double)((tiles_h + 255) / 256);
                 (void)wg;
-                half = p.half_m > 0 || (p.half_m == 0 && cost_h < 0.92 * cost_f);
+                half = p.half_m > 0 || (p.half_m == 0 && cost_h < 0.92 * cost_f) || epi == EPI_QKV_ALL;
                 use9 = true;
             }
             if (use9) {

@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
         // runs 20 % slower with the same instructions" of DESIGN.md 4.8: with the pin the loop is the plain kernel's 268
         // instructions (tools/isa_report.py) and fc2 / out-proj as producers cost + 1.7 / + 1.6 ms per step instead of
         // + 6.1 / + 2.9 (B = 64) — the fold now wins at every batch size (profiles/r4_ln_fold_acc_pin.log).
-        if constexpr (((LNF && EPI == EPI_RESID_F32) || EPI == EPI_QKV_ALL) && !HM) {
+        if constexpr (LNF && EPI == EPI_RESID_F32 && !HM) {
 #pragma unroll
             for (int nj = 0; nj < 8; ++nj)
 #pragma unroll
@@ -1005,7 +1005,7 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
             case EPI_QKV_ROPE: return launch9<T, EPI_QKV_ROPE, 0, false, true>(p, st);
             case EPI_V_T: return launch9<T, EPI_V_T, 0, false, true>(p, st);
             case EPI_GELU_T: return launch9<T, EPI_GELU_T, 0, false, true>(p, st);
-            case EPI_QKV_ALL: return launch9<T, EPI_QKV_ALL, 0, false, true>(p, st);
+            case EPI_QKV_ALL: return hipErrorInvalidValue;  // half-height tiles only (see gemm_qkv_one_launch)
         }
         return hipErrorInvalidValue;
     }
@@ -1030,7 +1030,7 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
             case EPI_RESID_F32: return launch9<T, EPI_RESID_F32>(p, st);
             case EPI_QKV_ROPE: return launch9<T, EPI_QKV_ROPE>(p, st);
             case EPI_V_T: return launch9<T, EPI_V_T>(p, st);
-            case EPI_QKV_ALL: return launch9<T, EPI_QKV_ALL>(p, st);
+            case EPI_QKV_ALL: return hipErrorInvalidValue;  // half-height tiles only (see gemm_qkv_one_launch)
         }
     }
     if constexpr (std::is_same<T, _Float16>::value) {

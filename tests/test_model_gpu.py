@@ -258,7 +258,10 @@ def test_degenerate_lengths():
         floor = C.floor_forward(sd, toks, L, H, repr_layers=[L])
         C.check_tensors(f"degenerate T={T} repr", out["representations"][L].cpu(), ref["representations"][L],
                         floor["representations"][L], nonpad)
-        C.check_tensors(f"degenerate T={T} logits", out["logits"].cpu(), ref["logits"], floor["logits"], nonpad)
+        # 4 - 5 positions x 33 logits: the max over ~150 noisy elements of two realisations of the same rounding noise
+        # (engine vs emulation) scatters far more than over the 10^6-element tensors SLACK was set on (1.31 x the floor
+        # measured on one box, with L2 at 1.15 x): slack 1.75 for both norms here
+        C.check_tensors(f"degenerate T={T} logits", out["logits"].cpu(), ref["logits"], floor["logits"], nonpad, slack=1.75)
 
 
 def test_row_guard_fails_loudly():

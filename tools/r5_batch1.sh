@@ -30,7 +30,6 @@ cp esm_amd/lib/libesmk_prev.so $LIB
 line r4_plain_b64
 ESM_AMD_LN_FOLD=1 line r4_fold_b64
 ESM_AMD_LN_FOLD=1 line r4_fold_b4 --batch 4 --steps 20 --warmup 5
-line r4_plain_b16 --batch 16
 cp esm_amd/lib/variants/libesmk_notie.so $LIB
 line notie_b64
 cp /tmp/libesmk_new.so $LIB
@@ -39,8 +38,6 @@ line new2_b64
 ESMK_QKV_ONE_LAUNCH=1 line new_onelaunch_b64
 line new_b16 --batch 16
 ESMK_QKV_ONE_LAUNCH=0 line new_b16_twolaunch --batch 16
-line new_b32 --batch 32
-ESMK_QKV_ONE_LAUNCH=1 line new_b32_onelaunch --batch 32
 line new_b4 --batch 4 --steps 20 --warmup 5
 line new_3b --workload esm2_3b_contacts --steps 4
 cp esm_amd/lib/libesmk_prev.so $LIB
