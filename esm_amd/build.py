@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libesmk.so")
-SOURCES = ["gemm.hip", "gemm8.hip", "gemm9.hip", "gemm32.hip", "attention.hip", "attention_w64.hip", "attention128.hip", "elementwise.hip", "contacts.hip", "engine.hip", "engine_msa.hip"]
+SOURCES = ["gemm.hip", "gemm8.hip", "gemm9.hip", "gemm32.hip", "attention.hip", "attention128.hip", "elementwise.hip", "contacts.hip", "engine.hip", "engine_msa.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_epi.h", "engine_internal.h", os.path.join("..", "..", "include", "esmk.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # build-time experiments (e.g. ESMK_HIPCC_EXTRA="-DESMK_G9_ALIGN=6"): part of the source hash, so such a library never

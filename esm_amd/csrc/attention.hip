@@ -85,6 +85,10 @@ constexpr float LAZY_LIMIT = 4096.f;
 // row sum on the matrix pipe (4 MFMAs of an all-ones A operand with the P fragments, Q re-read from an LDS image to free
 // the accumulator's 16 registers; exact, 168 VGPRs): 511 vs 452 us — the wave has to read the MFMA result back for the
 // overflow check before P.V may start, and that dependency costs more than the 32 adds.
+// Round 5: the same kernel with 64 query rows per wave (two 32-row blocks per wave sharing every K / V^T fragment read, one
+// barrier and one LDS-DMA round per 256 query rows, 256 registers -> 2 waves per SIMD; bit-identical, git bb4a853
+// attention_w64.hip): 13.9 vs 12.6 ms per step at B = 64, 1.48 vs 1.13 at B = 4 — the third resident wave is worth more than
+// half the LDS traffic (profiles/r5_attention_w64_and_resid_atomic_ab.log).  Removed.
 // HACK (timing experiments, results WRONG; ESMK_ATTN_HACK): 1 = no row-sum adds, 2 = no exponentials (p = score),
 // 4 = no P.V MFMAs, 8 = no QK^T MFMAs — which of VALU issue and the matrix pipe the kernel's time follows.
 template <typename T, int LAZY, bool BUF = true, int HACK = 0>
@@ -479,19 +483,6 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
 static std::atomic<int> g_attn_stagger{-1};
 constexpr int kAttnStaggerDefault = 0;
 void attention_set_stagger(int cycles) { g_attn_stagger = cycles < 0 ? 0 : cycles; }
-// 64 query rows per wave (attention_w64.hip; same bits): -1 = not read yet (ESMK_ATTN_W64), 0 = off, 1 = on.  Used for
-// padded / plain batches of at least kAttnW64MinT rows; token-packed batches
-// (128-row work items) stay on attn_fwd_kernel.
-static std::atomic<int> g_attn_w64{-1};
-constexpr int kAttnW64Default = 0;
-constexpr int kAttnW64MinT = 256;
-void attention_set_w64(int mode) {  // < 0: back to the environment's / the library's default
-    if (mode < 0) {
-        const char* e = getenv("ESMK_ATTN_W64");
-        mode = e ? atoi(e) : kAttnW64Default;
-    }
-    g_attn_w64 = mode;
-}
 
 hipError_t launch_attention(const void* q, const void* k, const void* vt, const float* key_bias,
                             const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
@@ -535,16 +526,6 @@ static hipError_t launch_attention_impl(const void* q, const void* k, const void
         }
     });
     const int stagger = g_attn_stagger.load();
-    static std::once_flag w64_once;
-    std::call_once(w64_once, [] {
-        if (g_attn_w64.load() < 0) {
-            const char* e = getenv("ESMK_ATTN_W64");
-            g_attn_w64 = e ? atoi(e) : kAttnW64Default;
-        }
-    });
-    const int w64 = g_attn_w64.load();
-    if (w64 > 0 && segs.work == nullptr && T >= kAttnW64MinT && (var & 1) && !(var & 2))
-        return launch_attention_w64(q, k, vt, key_bias, seq_info, ctx, lse, B, H, T, Tp, operand_dtype, fill_mode, any_pad, st);
 #define ESMK_ATTN_LAUNCH(TT, LZ, BF, ...)                                                                      \
     hipLaunchKernelGGL((attn_fwd_kernel<TT, LZ, BF, ##__VA_ARGS__>), grid, dim3(256), 0, st, (const TT*)q, (const TT*)k,   \
                        (const TT*)vt, key_bias, seq_info, (TT*)ctx, lse, H, B * H, nq, T, Tp, var & 1, fill_mode, any_pad, segs, stagger)

@@ -1195,10 +1195,6 @@ int esmk_op_linear_ln(const void* a_dev, const void* w_dev, const float* bias_de
 int esmk_debug_set(const char* key, double value) {
     if (!key) return fail("esmk_debug_set: null key");
     if (gemm_set_knob(key, value)) return 0;
-    if (strcmp(key, "attn_w64") == 0) {
-        attention_set_w64((int)value);
-        return 0;
-    }
     if (strcmp(key, "attn_stagger") == 0) {
         attention_set_stagger((int)value);
         return 0;

@@ -71,6 +71,10 @@ constexpr int Q_LDS = Q_EPI + 4 * Q_SLICE;   // 160 KiB
 // --------------------------------------------------------------------------------------------
 // fp32 outputs: 16 pieces of 32 rows x 32 columns (128-byte row segments).  EPI_RESID_F32 keeps D pieces of the
 // residual tile in flight.  Same arithmetic as epilogue8 (old + value).
+// (Round 5: the residual added in the L2 instead — one global_atomic_add_f32 per element, no return value, whole 128-byte
+// row segments per request; the same single IEEE addition, bit-identical on the GPU — costs the out-projection 11.7 instead
+// of 8.4 ms per step and fc2 24.6 instead of 23.0: the L2's atomic units do not sustain 84 M adds per launch.  Removed;
+// profiles/r5_attention_w64_and_resid_atomic_ab.log.)
 // NMI = 16-row blocks of the wave's block: 8 (128 rows), or 4 in the half-height kernel (64 rows).
 // SB: one 4 KiB piece buffer instead of two (the three-stage half-height kernel has 4 KiB of slice per wave; the LDS
 // executes a wave's accesses in order, so re-using the buffer is safe, only the overlap of write and read is lost).

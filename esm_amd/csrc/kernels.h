@@ -104,7 +104,6 @@ void gemm9_set_timing(unsigned long long* dev_buf);
 void gemm_set_impl(int impl, int var);
 // tuning knobs by name (esmk_debug_set): "resid_desync" (fraction of a tile's main loop), "resid_desync_group"
 bool gemm_set_knob(const char* key, double value);
-void attention_set_w64(int mode);  // attention.hip: 64 query rows per wave (attention_w64.hip), same bits; 0 off, 1 on
 void attention_set_stagger(int cycles);  // attention.hip: start-up stagger of co-resident workgroups (timing only)
 
 // ---- elementwise.hip -------------------------------------------------------------------
@@ -221,10 +220,6 @@ hipError_t launch_attention128_packed(const void* q, const void* k, const void* 
 hipError_t launch_attention(const void* q, const void* k, const void* vt, const float* key_bias,
                             const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
                             int operand_dtype, hipStream_t st);
-// attention_w64.hip: head_dim 64, 64 query rows per wave (bit-identical to launch_attention's kernel)
-hipError_t launch_attention_w64(const void* q, const void* k, const void* vt, const float* key_bias,
-                                const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
-                                int operand_dtype, int fill_mode, const int* any_pad, hipStream_t st);
 // attention128.hip: head_dim 128 (esm2_t48_15B)
 hipError_t launch_attention128(const void* q, const void* k, const void* vt, const float* key_bias,
                                const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
