@@ -631,6 +631,21 @@ def run_msa1b(args, dist, rank, world, dev):
         result["parity"] = {"rel_repr_diff_vs_cpu": ((r_gpu - r_ref).abs().max() / r_ref.abs().max()).item(),
                             "rel_l2_repr_diff_vs_cpu": ((r_gpu - r_ref).norm() / r_ref.norm()).item(),
                             **argmax_report(got["logits"].float().cpu(), ref["logits"].float())}
+        try:  # the floor of any 16-bit-operand engine on exactly this sample (as the 650M / 3B lines report it)
+            from oracle.msa_oracle import msa_operand_floor
+
+            c0 = time.perf_counter()
+            fl = msa_operand_floor(sd, small, L, H, repr_layers=[L])
+            f_r = fl["representations"][L].double()
+            lg_f, lg_r = fl["logits"].double(), ref["logits"].double()
+            result["parity"]["operand_floor_same_inputs"] = {
+                "rel_repr_diff_vs_cpu": ((f_r - r_ref).abs().max() / r_ref.abs().max()).item(),
+                "rel_l2_repr_diff_vs_cpu": ((f_r - r_ref).norm() / r_ref.norm()).item(),
+                "logits_rel_diff": ((lg_f - lg_r).abs().max() / lg_r.abs().max()).item(),
+                "seconds": round(time.perf_counter() - c0, 1),
+                "what": "fp32 oracle with f16 rounding injected at every operand point (weights, GEMM inputs, q / k / v, P), same rows"}
+        except Exception as e:  # the floor is a report, never a reason to lose the line
+            result["parity"]["operand_floor_same_inputs"] = {"error": str(e)[:200]}
     return result
 
 

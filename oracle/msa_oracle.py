@@ -124,3 +124,53 @@ def msa_forward(sd, tokens, num_layers, heads, repr_layers=(), need_head_weights
         if return_contacts:
             out["contacts"] = contact_head(sd, tokens, out["row_attentions"], eos_idx, prepend_bos, append_eos)
     return out
+
+
+# ---- the 16-bit-operand FLOOR of this model (as esm2_oracle's `inject`): the same forward with rounding injected at the
+# engine's rounding points — linear-layer weights and inputs, the q / k / v operands of the attention contractions, the
+# softmax probabilities.  tools/msa_precision_study.py (per-group study) and bench.py (floor next to the engine's
+# parity numbers on the same sample) use it; nothing in the product does.
+import torch as _torch  # the real modules: `F` / `torch` of this module are swapped for proxies during a rounded run
+import torch.nn.functional as _F
+
+
+class OperandRounding:
+    def __init__(self, weights=None, acts=None, qkv=None, probs=None):
+        self.weights, self.acts, self.qkv, self.probs = weights, acts, qkv, probs
+
+    @staticmethod
+    def _r(t, dt):
+        return t.to(dt).float() if dt is not None else t
+
+    def linear(self, x, w, b=None):
+        return _F.linear(self._r(x, self.acts), self._r(w, self.weights), b)
+
+    def einsum(self, eq, a, b):
+        if eq.startswith("hnij") or eq.startswith("hcnij"):  # probs x v
+            return _torch.einsum(eq, self._r(a, self.probs), self._r(b, self.qkv))
+        return _torch.einsum(eq, self._r(a, self.qkv), self._r(b, self.qkv))
+
+
+class _Proxy:
+    def __init__(self, real, name, fn):
+        self._real, self._name, self._fn = real, name, fn
+
+    def __getattr__(self, k):
+        return self._fn if k == self._name else getattr(self._real, k)
+
+
+def msa_forward_rounded(rounding, sd, tokens, num_layers, heads, **kw):
+    """msa_forward with `rounding` (an OperandRounding) applied at every F.linear / torch.einsum of this module."""
+    g = globals()
+    real_F, real_torch = g["F"], g["torch"]
+    g["F"], g["torch"] = _Proxy(real_F, "linear", rounding.linear), _Proxy(real_torch, "einsum", rounding.einsum)
+    try:
+        return msa_forward(sd, tokens, num_layers, heads, **kw)
+    finally:
+        g["F"], g["torch"] = real_F, real_torch
+
+
+def msa_operand_floor(sd, tokens, num_layers, heads, dtype=None, **kw):
+    """The floor: every MFMA operand of the engine rounded to `dtype` (default fp16)."""
+    dt = dtype or _torch.float16
+    return msa_forward_rounded(OperandRounding(weights=dt, acts=dt, qkv=dt, probs=dt), sd, tokens, num_layers, heads, **kw)
