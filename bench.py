@@ -432,7 +432,9 @@ def operand_floor_report(sd, toks_cpu, L, H, r_ref):
 # time limit; nothing in here can cost the flagship line.
 SECONDARY = [  # --quick-baseline: the children's own CPU-oracle sample (parity + cpu_baseline), sized for a few seconds
     ("msa1b", ["--workload", "msa1b", "--quick-baseline"], 120),
-    ("extract_650m", ["--workload", "extract_650m", "--steps", "8", "--warmup", "2", "--quick-baseline"], 150),
+    # 24 batches: the timed region ends when the writer threads have closed the LAST file, i.e. it contains one un-overlapped
+    # drain (device->host + 64 files of 5.2 MB, ~80 ms) whatever its length — at 8 batches that was 10 % of the figure
+    ("extract_650m", ["--workload", "extract_650m", "--steps", "24", "--warmup", "2", "--quick-baseline"], 150),
     ("esm2_3b_contacts", ["--workload", "esm2_3b_contacts", "--steps", "4", "--quick-baseline"], 200),
     # the headline configuration WITHOUT the LayerNorm fold (round 4's default path), same run, same box
     ("esm2_650m_plain", ["--workload", "esm2_650m", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-secondary",

@@ -142,7 +142,7 @@ def test_secondary_workloads_glue(monkeypatch):
     for name, r in out.items():
         assert "error" not in r, (name, r)
         assert r["metric"].startswith("protocol-test") and r["ms_per_step"] >= 4.5 and r["wall_s"] > 0
-    assert out["esm2_3b_contacts"]["steps"] == 4 and out["extract_650m"]["steps"] == 8 and out["extract_650m"]["warmup"] == 2
+    assert out["esm2_3b_contacts"]["steps"] == 4 and out["extract_650m"]["steps"] == 24 and out["extract_650m"]["warmup"] == 2
     # a child that fails or overruns its limit is an entry with "error", not an exception
     monkeypatch.setattr(bench, "SECONDARY", [("bad_flag", ["--no-such-flag"], 60), ("too_slow", ["--steps", "400"], 1)])
     monkeypatch.setattr(bench, "SECONDARY_MIN_S", 0.5)
