@@ -17,6 +17,10 @@ r4_parity_budget_study.log).  Hence:
 SLACK = 1.25: two realisations of "the maximum of the same noise over the tensor" (engine vs emulation: different
 summation orders, fused vs separate roundings) differ by up to ~15 % on the committed fixtures; a real defect — one
 un-normalised row, a missed mask, a wrong rounding point — shows as 2 x or more, and in L2.
+Contact logits get CONTACT_SLACK = 1.5: their figure is ONE number per map — the largest logit error over ~10^5 pairs
+relative to the logit range — and logits of near-saturated probabilities are heavy-tailed, so two realisations of that maximum
+differ more: engine / floor measured 0.64 ... 1.28 over the five full-size maps in the two engine modes (fold / plain,
+profiles/r5_gpu_tests_contract_lines.txt, r5_gpu_tests_plain_mode.txt).
 Integer outputs (tokens, argmax wherever the reference's top-2 margin exceeds twice the logit error) are exact.
 """
 import json
@@ -26,6 +30,7 @@ import torch
 
 CONTRACT = 1e-3
 SLACK = 1.25
+CONTACT_SLACK = 1.5
 _FLOORS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "operand_floors.json")
 
 

@@ -157,7 +157,7 @@ def test_3b_dims_contacts_against_oracle():
         _, zrel = C.contact_logit_errors(c[b, sl, sl], cr[b, sl, sl])
         _, zfl = C.contact_logit_errors(cf[b, sl, sl], cr[b, sl, sl])
         print(f"3B-dims T=96 seq {b}: contact prob err {perr:.2e}")
-        C.check(f"3B-dims T=96 contact logits seq {b}", zrel, zrel, zfl, zfl)
+        C.check(f"3B-dims T=96 contact logits seq {b}", zrel, zrel, zfl, zfl, slack=C.CONTACT_SLACK)
         assert perr < 2e-2, (b, perr)
     # the same map without the [2,36,40,96,96] attention tensor (csrc/contacts.hip; 1440 channels, 40 heads)
     with torch.no_grad():

@@ -45,7 +45,7 @@ def test_stub_struct_and_host_calls():
 
 
 @pytest.mark.gpu
-def test_stub_forward_equals_package_forward():
+def test_stub_forward_equals_package_forward(monkeypatch):
     import esm
     from esm_amd.synth import synth_esm2_state_dict, synth_tokens
 
@@ -60,6 +60,9 @@ def test_stub_forward_equals_package_forward():
     toks = toks.cuda()
     with torch.no_grad():
         want = m(toks, repr_layers=[0, 2, L], return_contacts=True)
+        # the stub leaves esmk_config.ln_fold at 0 = "the library's default"; a suite run with ESM_AMD_LN_FOLD=0 (the package's
+        # switch) puts the package in the plain mode, so the library's own switch gives the stub the same one
+        monkeypatch.setenv("ESMK_LN_FOLD", "1" if m.ln_fold_active() else "0")
         got = stub.forward(m, toks, repr_layers=[0, 2, L], return_contacts=True)
     assert sorted(got) == sorted(want) and sorted(got["representations"]) == [0, 2, L]
     for k in ("logits", "attentions", "contacts"):
