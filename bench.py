@@ -680,6 +680,16 @@ def run_extract_650m(args, dist, rank, world, dev):
     alphabet = esm.Alphabet.from_architecture("ESM-1b")
     fwd = make_embed_fn(model, varlen=True)
     base = args.out_dir or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
+    # every result file of the warm-up and the timed run exists at the end (n_files / file bytes are reported): 5.3 MB per sequence
+    need = (args.steps + max(args.warmup, 1)) * batch * (args.seq_len * E * 4 + (1 << 16)) * 1.05
+    if not args.out_dir and shutil.disk_usage(base).free < need:
+        alt = tempfile.gettempdir()
+        if shutil.disk_usage(alt).free >= need:
+            base = alt
+        else:  # a small box: time what fits (never fewer than 4 batches) rather than fail the line
+            free = max(shutil.disk_usage(base).free, shutil.disk_usage(alt).free)
+            base = base if shutil.disk_usage(base).free >= shutil.disk_usage(alt).free else alt
+            args.steps = max(4, min(args.steps, int(free / (need / (args.steps + max(args.warmup, 1)))) - max(args.warmup, 1) - 1))
     out_dir = pathlib.Path(tempfile.mkdtemp(prefix="esm_amd_bench_", dir=base))
     include = ["mean", "per_tok"]
 
