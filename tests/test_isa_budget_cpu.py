@@ -1,0 +1,80 @@
+"""Static regression test of the EMITTED code of the two hot kernels (CPU only: hipcc cross-compiles gfx950).
+
+The rates of gemm9_kernel and attn_fwd_kernel rest on properties of the instruction stream that neither a GPU parity
+test nor a reading of the source shows, and that a source edit or a compiler update can break silently (DESIGN.md
+notebook 4.1b, 4.8: "the main loop that runs 20 % slower with the same instructions" was an accumulator quad carried
+through VGPRs across the K-loop edge — one v_accvgpr round trip per K tile, found only in the ISA):
+
+  gemm9, every shipped instantiation (VAR = 0):
+    * steady-state K-tile block: 128 MFMAs in at most 268 instructions (full-height tiles), 64 in at most 170 (half-height);
+      no scratch access, no v_accvgpr move;
+    * first-K-tile block (round 5, tied in-place MFMA): at most 330 / 215 instructions, at most 32 v_accvgpr writes (the bias),
+      at most 8 scratch operations;
+  attention: attn_fwd_kernel needs at most 168 VGPRs (three waves per SIMD) and no scratch.
+
+tools/isa_report.py prints the same table for a human."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+HIPCC = "/opt/rocm/bin/hipcc"
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+@pytest.fixture(scope="module")
+def asm():
+    import isa_report
+
+    tmp = tempfile.mkdtemp(prefix="isa_budget_")
+    out = {}
+    for src in ("gemm9.hip", "attention.hip"):
+        path = os.path.join(tmp, src + ".s")
+        isa_report.compile_asm(os.path.join(ROOT, "esm_amd", "csrc"), src, path)
+        out[src] = path
+    return isa_report, out
+
+
+def test_gemm9_k_loops_stay_inside_their_instruction_budget(asm):
+    isa, paths = asm
+    path = paths["gemm9.hip"]
+    meta = isa.meta(path)
+    shipped = [k for k in meta if re.search(r"gemm9_kernelI\w+?Li\d+ELi0ELb[01]ELb[01]E", k)]
+    assert len(shipped) >= 40, len(shipped)  # 7 - 8 epilogues x 2 heights x fold / plain x 2 operand dtypes
+    bad = []
+    for k in shipped:
+        half = "ELi0ELb1ELb" in k
+        blocks = isa.loops(path, k)
+        want_mfma, steady_max, first_max = (64, 170, 215) if half else (128, 268, 330)
+        if not blocks:
+            bad.append((k, "no K-loop block found"))
+            continue
+        steady = [b for b in blocks if b[3] == 0 and b[0] <= steady_max]
+        if not steady:
+            bad.append((k, "no steady-state block inside the budget", blocks))
+        for n_ins, n_mfma, n_scr, n_acc in blocks:
+            if n_mfma != want_mfma:
+                bad.append((k, "MFMAs per K-tile block", n_mfma))
+            # (the LM head's fp32 GELU instantiation, once per forward, carries 8 scratch operations in its first block)
+            if n_ins > first_max or n_acc > 32 or n_scr > 8:
+                bad.append((k, "first-K-tile block over budget (instructions, scratch ops, v_accvgpr)", (n_ins, n_scr, n_acc)))
+            if n_ins <= steady_max and n_acc == 0 and n_scr != 0:
+                bad.append((k, "scratch access in a steady-state block", n_scr))
+    assert not bad, bad[:8]
+
+
+def test_attention_keeps_three_waves_per_simd(asm):
+    isa, paths = asm
+    meta = isa.meta(paths["attention.hip"])
+    # the shipped instantiations: lazy offset, buffer-load staging, nothing removed (LAZY = 1, BUF = true, HACK = 0), f16 and bf16
+    kernels = [k for k in meta if "attn_fwd_kernel" in k and "Li1ELb1ELi0EE" in k]
+    assert len(kernels) == 2, kernels
+    for k in kernels:
+        vgpr, accum, scratch = meta[k]
+        assert vgpr <= 168 and scratch == 0, (k, vgpr, scratch)
