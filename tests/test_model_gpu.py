@@ -340,3 +340,32 @@ def test_half_and_bf16_models():
     outb = mb(toks.cuda(), repr_layers=[2])
     assert outb["logits"].dtype == torch.bfloat16
     assert rel_err(outb["representations"][2].float().cpu(), ref["representations"][2]) < 3e-2
+
+
+def test_sequences_longer_than_1024_tokens():
+    """ESM-2 has rotary positions, so nothing in the reference limits the length (esm2.py:77-147; extract.py truncates to
+    1022 only by its own default).  A 4100-token sequence next to a 1500-token one: 65 key tiles, a padded batch whose
+    second sequence skips 41 all-pad tiles, RoPE tables beyond the first 1024 rows; with contacts on a 2100-token batch."""
+    L, E, H = 2, 128, 2
+    model, sd = build(L, E, H, seed=31)
+    toks = synth_tokens(2, 4098, seed=5)
+    toks[1, 1499] = 2
+    toks[1, 1500:] = 1
+    with torch.no_grad():
+        out = model(toks.cuda(), repr_layers=[L])
+        pk = model.forward_varlen(toks.cuda(), repr_layers=[L], min_saving=None)
+    ref = esm2_forward(sd, toks, L, H, repr_layers=[L])
+    floor = C.floor_forward(sd, toks, L, H, repr_layers=[L])
+    nonpad = toks.ne(1)
+    assert torch.isfinite(out["representations"][L][nonpad.cuda()]).all()
+    C.check_tensors("T=4100 repr", out["representations"][L].cpu(), ref["representations"][L], floor["representations"][L], nonpad)
+    C.check_tensors("T=4100 logits", out["logits"].cpu(), ref["logits"], floor["logits"], nonpad)
+    assert torch.equal(pk["representations"][L][nonpad.cuda()], out["representations"][L][nonpad.cuda()])
+    toks = synth_tokens(1, 2098, seed=6)
+    with torch.no_grad():
+        outc = model(toks.cuda(), repr_layers=[L], return_contacts=True)
+        fused = model.predict_contacts(toks.cuda())
+    refc = esm2_forward(sd, toks, L, H, repr_layers=[L], return_contacts=True)
+    assert outc["contacts"].shape == refc["contacts"].shape == (1, 2098, 2098)
+    assert (outc["contacts"].cpu() - refc["contacts"]).abs().max().item() < 5e-3
+    assert (fused.cpu() - outc["contacts"].cpu()).abs().max().item() < 1e-4
