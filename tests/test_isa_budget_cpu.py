@@ -6,9 +6,9 @@ notebook 4.1b, 4.8: "the main loop that runs 20 % slower with the same instructi
 through VGPRs across the K-loop edge — one v_accvgpr round trip per K tile, found only in the ISA):
 
   gemm9, every shipped instantiation (VAR = 0):
-    * steady-state K-tile block: 128 MFMAs in at most 268 instructions (full-height tiles), 64 in at most 170 (half-height);
+    * steady-state K-tile block: 128 MFMAs in 268 (+ 4 of slack) instructions (full-height tiles), 64 in 170 (half-height);
       no scratch access, no v_accvgpr move;
-    * first-K-tile block (round 5, tied in-place MFMA): at most 330 / 215 instructions, at most 32 v_accvgpr writes (the bias),
+    * first-K-tile block (round 5, tied in-place MFMA): at most 334 / 219 instructions, at most 32 v_accvgpr writes (the bias),
       at most 8 scratch operations;
   attention: attn_fwd_kernel needs at most 168 VGPRs (three waves per SIMD) and no scratch.
 
@@ -51,7 +51,10 @@ def test_gemm9_k_loops_stay_inside_their_instruction_budget(asm):
     for k in shipped:
         half = "ELi0ELb1ELb" in k
         blocks = isa.loops(path, k)
-        want_mfma, steady_max, first_max = (64, 170, 215) if half else (128, 268, 330)
+        # measured 268 / 170 and 311 - 328 / 200 - 210; hipcc is not bit-reproducible for every instantiation (tools/isa_report.py
+        # --twice), so the instruction bounds carry 4 of slack — the regressions this test exists for (an accumulator quad through
+        # VGPRs, a spill in the loop) show as v_accvgpr / scratch operations, which get none
+        want_mfma, steady_max, first_max = (64, 174, 219) if half else (128, 272, 334)
         if not blocks:
             bad.append((k, "no K-loop block found"))
             continue
