@@ -402,13 +402,13 @@ def run_esm2_650m(args, dist, rank, world, dev):
             "rel_l2_repr_diff_vs_cpu": ((r_gpu - r_ref).norm() / r_ref.norm()).item(),
             **amax, "sample_sequences": 4,
         }
-        result["parity"]["operand_floor_same_inputs"] = operand_floor_report(sd, s4, L, H, r_ref)
+        result["parity"]["operand_floor_same_inputs"] = operand_floor_report(sd, s4, L, H, r_ref, ref["logits"])
         if args.save_parity_ref:  # for the secondary 650M lines (other batch / fold settings): same sequences, same reference
             torch.save({"tokens": s4, "repr": ref["representations"][L], "logits": ref["logits"]}, args.save_parity_ref)
     return result
 
 
-def operand_floor_report(sd, toks_cpu, L, H, r_ref):
+def operand_floor_report(sd, toks_cpu, L, H, r_ref, logits_ref=None):
     """The CPU sample once more through the oracle with every MFMA operand (weights, GEMM inputs, q, k, v, P) rounded
     to the operand dtype: the accuracy floor of ANY 16-bit-operand engine on these inputs, to read the engine's own
     `parity` numbers against.  Test infrastructure on the CPU leg only; never costs the JSON line."""
@@ -419,10 +419,16 @@ def operand_floor_report(sd, toks_cpu, L, H, r_ref):
         # f16x2 (split weights): the floor of that mode keeps the weights exact
         kinds = [k for k in ALL_OPERANDS if not (operand_name() == "f16x2" and k == "W")]
         fl = esm2_forward(sd, toks_cpu, L, H, repr_layers=[L], inject=(frozenset(kinds), odt))
+        lg = fl["logits"].double()
         fl = fl["representations"][L].double()
-        return {"rel_repr_diff_vs_cpu": ((fl - r_ref).abs().max() / r_ref.abs().max()).item(),
-                "rel_l2_repr_diff_vs_cpu": ((fl - r_ref).norm() / r_ref.norm()).item(),
-                "what": f"fp32 oracle with {operand_name()} rounding injected at every operand point, same sequences"}
+        rep = {"rel_repr_diff_vs_cpu": ((fl - r_ref).abs().max() / r_ref.abs().max()).item(),
+               "rel_l2_repr_diff_vs_cpu": ((fl - r_ref).norm() / r_ref.norm()).item(),
+               "what": f"fp32 oracle with {operand_name()} rounding injected at every operand point, same sequences"}
+        if logits_ref is not None:  # the floor of the logits as well: parity.logits_rel_diff is to be read against it
+            lr = logits_ref.double()
+            rep["logits_rel_diff"] = ((lg - lr).abs().max() / lr.abs().max()).item()
+            rep["logits_argmax_agreement"] = (lg.argmax(-1) == lr.argmax(-1)).double().mean().item()
+        return rep
     except Exception as e:
         return {"error": str(e)}
 
