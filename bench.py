@@ -75,10 +75,21 @@ def argmax_report(logits, ref_logits):
     return {"logits_argmax_agreement": same.float().mean().item(),
             "logits_max_abs_diff": err,
             "logits_rel_diff": err / max(ref_logits.abs().max().item(), 1e-30),
+            **logits_l2_report(logits, ref_logits),
             "positions": n,
             "decided_positions": int(decided.sum().item()),
             "undecided_fraction": round(1.0 - decided.sum().item() / n, 5),
             "argmax_agreement_where_decided": same[decided].float().mean().item() if bool(decided.any()) else None}
+
+
+def logits_l2_report(logits, ref_logits):
+    """L2 error of the logits, and its split into the row-independent part (the mean error vector over all positions: ONE
+    draw of the weight-rounding bias per model and operand form) and the token-dependent rest."""
+    d = (logits.double() - ref_logits.double()).reshape(-1, ref_logits.shape[-1])
+    c = d.mean(0, keepdim=True)
+    n = max(ref_logits.double().norm().item(), 1e-30)
+    return {"logits_rel_l2_diff": d.norm().item() / n, "logits_rel_l2_row_common": c.norm().item() * d.shape[0] ** 0.5 / n,
+            "logits_rel_l2_token_dependent": (d - c).norm().item() / n}
 
 
 PER_RANK_MS = []  # each rank's own ms per step of the last timed region (before it waits for the others)
@@ -402,32 +413,36 @@ def run_esm2_650m(args, dist, rank, world, dev):
             "rel_l2_repr_diff_vs_cpu": ((r_gpu - r_ref).norm() / r_ref.norm()).item(),
             **amax, "sample_sequences": 4,
         }
-        result["parity"]["operand_floor_same_inputs"] = operand_floor_report(sd, s4, L, H, r_ref, ref["logits"])
+        result["parity"]["operand_floor_same_inputs"] = operand_floor_report(sd, s4, L, H, r_ref, ref["logits"], fold=bool(model.ln_fold_active()))
         if args.save_parity_ref:  # for the secondary 650M lines (other batch / fold settings): same sequences, same reference
             torch.save({"tokens": s4, "repr": ref["representations"][L], "logits": ref["logits"]}, args.save_parity_ref)
     return result
 
 
-def operand_floor_report(sd, toks_cpu, L, H, r_ref, logits_ref=None):
+def operand_floor_report(sd, toks_cpu, L, H, r_ref, logits_ref=None, fold=False):
     """The CPU sample once more through the oracle with every MFMA operand (weights, GEMM inputs, q, k, v, P) rounded
     to the operand dtype: the accuracy floor of ANY 16-bit-operand engine on these inputs, to read the engine's own
-    `parity` numbers against.  Test infrastructure on the CPU leg only; never costs the JSON line."""
+    `parity` numbers against — in the FORM the engine ran in (`fold`: the LayerNorm-fold form of the
+    LayerNorm -> Linear pairs, oracle "FOLD" injection; one model's two forms differ by a draw of the weight-rounding bias).
+    Test infrastructure on the CPU leg only; never costs the JSON line."""
     try:
         from oracle.esm2_oracle import ALL_OPERANDS, esm2_forward
 
         odt = torch.bfloat16 if operand_name() == "bf16" else torch.float16
         # f16x2 (split weights): the floor of that mode keeps the weights exact
-        kinds = [k for k in ALL_OPERANDS if not (operand_name() == "f16x2" and k == "W")]
+        kinds = [k for k in ALL_OPERANDS if not (operand_name() == "f16x2" and k == "W")] + (["FOLD"] if fold else [])
         fl = esm2_forward(sd, toks_cpu, L, H, repr_layers=[L], inject=(frozenset(kinds), odt))
         lg = fl["logits"].double()
         fl = fl["representations"][L].double()
         rep = {"rel_repr_diff_vs_cpu": ((fl - r_ref).abs().max() / r_ref.abs().max()).item(),
                "rel_l2_repr_diff_vs_cpu": ((fl - r_ref).norm() / r_ref.norm()).item(),
+               "form": "ln_fold" if fold else "plain",
                "what": f"fp32 oracle with {operand_name()} rounding injected at every operand point, same sequences"}
         if logits_ref is not None:  # the floor of the logits as well: parity.logits_rel_diff is to be read against it
             lr = logits_ref.double()
             rep["logits_rel_diff"] = ((lg - lr).abs().max() / lr.abs().max()).item()
             rep["logits_argmax_agreement"] = (lg.argmax(-1) == lr.argmax(-1)).double().mean().item()
+            rep.update(logits_l2_report(lg, lr))
         return rep
     except Exception as e:
         return {"error": str(e)}
@@ -563,14 +578,17 @@ def run_esm2_3b_contacts(args, dist, rank, world, dev):
                             "rel_l2_repr_diff_vs_cpu": ((r_gpu - r_ref).norm() / r_ref.norm()).item(),
                             **argmax_report(out["logits"].float().cpu(), ref["logits"].float()), "sample_residues": n_small}
         try:  # the fp16-operand floor on the same sample: what any 16-bit-operand engine gets at best
-            fl = esm2_forward(sd, small, L, H, repr_layers=[L], return_contacts=True, inject=(frozenset(ALL_OPERANDS), torch.float16))
+            fold = bool(model.ln_fold_active())  # the floor in the form the engine ran in
+            fl = esm2_forward(sd, small, L, H, repr_layers=[L], return_contacts=True,
+                              inject=(frozenset(ALL_OPERANDS + (("FOLD",) if fold else ())), torch.float16))
             zf = lg(fl["contacts"])
             f_rep = fl["representations"][L].double()
             result["parity"]["operand_floor_same_inputs"] = {
                 "contacts_logit_diff_rel_to_range": ((zf - zr).abs().max() / zr.abs().max()).item(),
                 "rel_repr_diff_vs_cpu": ((f_rep - r_ref).abs().max() / r_ref.abs().max()).item(),
                 "rel_l2_repr_diff_vs_cpu": ((f_rep - r_ref).norm() / r_ref.norm()).item(),
-                "logits_rel_diff": ((fl["logits"] - ref["logits"]).abs().max() / ref["logits"].abs().max()).item()}
+                "logits_rel_diff": ((fl["logits"] - ref["logits"]).abs().max() / ref["logits"].abs().max()).item(),
+                "form": "ln_fold" if fold else "plain", **logits_l2_report(fl["logits"], ref["logits"])}
         except Exception as e:
             result["parity"]["operand_floor_same_inputs"] = {"error": str(e)[:200]}
     return result

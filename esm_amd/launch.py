@@ -48,8 +48,12 @@ def rank_cpu_slice(local_rank: int, local_world: int, cpus=None):
         with open(f"/sys/devices/system/cpu/cpu{cpus[0]}/topology/thread_siblings_list") as fh:
             txt = fh.read().strip()
         first = sorted(int(x) for part in txt.split(",") for x in (range(int(part.split("-")[0]), int(part.split("-")[-1]) + 1)))
-        if len(first) == 2 and first[1] - first[0] == n // 2 and set(range(cpus[0], cpus[0] + n)) == set(cpus):
-            sib = {c: c + n // 2 for c in cpus[: n // 2]}
+        # two hardware threads per core, numbered [a, a + h) and their siblings [b, b + h): the whole host (b = a + h) or one
+        # NUMA node's set (e.g. 0-63 + 128-191)
+        h = n // 2
+        if (len(first) == 2 and first[0] == cpus[0] and cpus[:h] == list(range(cpus[0], cpus[0] + h))
+                and cpus[h:] == list(range(first[1], first[1] + h))):
+            sib = {c: c + (first[1] - first[0]) for c in cpus[:h]}
     except (OSError, ValueError):
         pass
     if sib:  # cores [a, b) and their siblings
@@ -61,23 +65,30 @@ def rank_cpu_slice(local_rank: int, local_world: int, cpus=None):
     return set(cpus[local_rank * per:(local_rank + 1) * per])
 
 
-def pin_rank_cpus(local_rank: int, local_world: int, force: bool = False):
+def pin_rank_cpus(local_rank: int, local_world: int, force: bool = False, peers=None):
     """Restrict this process (and the threads it starts) to its share of the host's CPUs.  ``ESM_AMD_NO_AFFINITY=1``
     switches it off.  Returns the CPU set in effect.
 
-    A CPU set that already looks PER-RANK is kept as it is: when the launcher (torchrun NUMA binding, taskset, a cgroup
-    per rank) gave this rank at most a 1 / local_world share of the host, slicing it again would leave e.g. 2 of 16 CPUs
-    to the tokeniser, the writer threads and the GPU driver thread.  A restricted set that is still LARGER than
-    one rank's share is a set all ranks of the job share (docker --cpuset-cpus, a Slurm job cpuset): every rank sees the
-    same CPUs, so it is sliced like the whole host would be — otherwise 8 ranks' threads contend on the shared CPUs
-    (ADVICE r4).  ``force`` slices regardless."""
+    ``peers``: the affinity sets of ALL local ranks (index = local rank; init_ranks gathers them once the process group is
+    up).  With them the decision is exact: ranks whose sets are identical share that set and it is sliced among exactly
+    those ranks (all ranks of a docker / Slurm cpuset, or the 4 ranks of one NUMA node under torchrun's NUMA binding); a
+    set nobody else has is a per-rank set and is kept (the size of a set alone cannot tell a node's set from a
+    job's).  Without ``peers`` (no process group yet / a single caller): a set of at most one rank's share of the host is
+    kept, a larger restricted set is taken as shared by all local ranks, the whole host is sliced
+    by local_world.  ``force`` slices by local_world regardless."""
     if os.environ.get("ESM_AMD_NO_AFFINITY", "0") == "1" or not hasattr(os, "sched_setaffinity"):
         return set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set()
     have = os.sched_getaffinity(0)
     host = os.cpu_count() or len(have)
-    if not force and local_world > 1 and len(have) <= host // local_world:
+    if peers is None and not force and local_world > 1 and len(have) <= host // local_world:
         return set(have)  # a per-rank set from whoever started us: not ours to narrow further
-    want = rank_cpu_slice(local_rank, local_world)
+    if peers is not None and not force:
+        same = [r for r in range(len(peers)) if set(peers[r]) == set(peers[local_rank])]
+        if len(same) <= 1:
+            return set(have)
+        want = rank_cpu_slice(same.index(local_rank), len(same), cpus=have)
+    else:
+        want = rank_cpu_slice(local_rank, local_world, cpus=have)
     try:
         os.sched_setaffinity(0, want)
     except OSError:
@@ -102,9 +113,6 @@ def init_ranks(expect_world: int, backend: str):
 
     # one node: every rank gets its own share of the host's CPUs (tokeniser + writer threads + GPU driver thread)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    cpus = pin_rank_cpus(local_rank, local_world)
-    if cpus:
-        torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus))))
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
@@ -119,4 +127,12 @@ def init_ranks(expect_world: int, backend: str):
     probe = torch.tensor([float(rank)], device=dev)
     dist.all_reduce(probe)
     assert probe.item() == world * (world - 1) / 2, "all_reduce over the ranks returned a wrong sum"
+    # every rank's share of the host's CPUs, decided on the affinity sets of all local ranks (one node: world == local_world)
+    peers = None
+    if hasattr(os, "sched_getaffinity") and world == local_world:
+        peers = [None] * world
+        dist.all_gather_object(peers, sorted(os.sched_getaffinity(0)))
+    cpus = pin_rank_cpus(local_rank, local_world, peers=peers)
+    if cpus:
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus))))
     return dist, rank, world, local_rank

@@ -20,6 +20,14 @@ unrounded q / k — study hook for a split-q contact sweep; "A!qk": group A is n
 v, o, fc1, fc2); "W8": weights as fp16 + a block-scaled fp8 remainder; ``inject_head``: the LM head's own setting).  With all five it is the accuracy FLOOR of any engine
 that feeds 16-bit operands to fp32-accumulating matrix cores; tools/esm2_precision_study.py and the parity tests
 read the HIP engine's error against it.
+
+"FOLD" in the kinds: the LayerNorm -> Linear pairs (q / k / v projections, fc1) in the engine's LayerNorm-fold FORM
+(esm_amd/csrc/kernels.h GemmArgs::ln_part; same real-arithmetic value as modules.py:113,137 + the nn.Linear behind them):
+the A operand is the rounded raw row  fp16(x - m_prev)  (m_prev: the row's mean at the PREVIOUS LayerNorm point — any
+per-row constant cancels against centred weights), the weights are  fp16(gamma W - rowmean(gamma W)),  and the value is
+rstd * acc + (b + W . beta)  with fp32 mean / rstd.  Same number of roundings as the plain form at different points: the
+floor "in the fold's form" (profiles/r6_ln_fold_logits_study.log: the two forms differ by one draw of the weight-rounding
+bias per model, not systematically).
 """
 import math
 
@@ -86,20 +94,23 @@ def apply_rope(x, cos, sin):
     return x * cos + rot * sin
 
 
-def attention_layer(sd, prefix, x, heads, pad_mask, need_weights, use_rope=True, inject=None):
+def attention_layer(sd, prefix, x, heads, pad_mask, need_weights, use_rope=True, inject=None, qkv=None, shape=None):
     """Self-attention of one TransformerLayer on x [B,T,E] (reference works on [T,B,E], the math
     is layout independent).  reference esm/multihead_attention.py:256-261 (projections, q scaling),
     :280-284 (head split), :354-355 (rotary), :357 (scores), :368-374 (key padding -inf),
     :379-380 (fp32 softmax), :387-395 (PV, merge, out_proj)."""
-    B, T, E = x.shape
+    B, T, E = x.shape if shape is None else shape
     d = E // heads
     p = prefix + "self_attn."
-    q = _linear(x, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"], inject, "qk") * (d ** -0.5)
-    k = _linear(x, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"], inject, "qk")
-    v = _linear(x, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"], inject, "v")
+    if qkv is not None:  # the projections in the LayerNorm-fold form (FoldRows.linear); x is not used
+        q, k, v = qkv("q") * (d ** -0.5), qkv("k"), qkv("v")
+    else:
+        q = _linear(x, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"], inject, "qk") * (d ** -0.5)
+        k = _linear(x, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"], inject, "qk")
+        v = _linear(x, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"], inject, "v")
     q, k, v = (t.view(B, T, heads, d).transpose(1, 2) for t in (q, k, v))  # [B,H,T,d]
     if use_rope:  # ESM-2 (TransformerLayer(use_rotary_embeddings=True), esm2.py:57-66); ESM-1b has none
-        cos, sin = rope_tables(T, d, x.device)
+        cos, sin = rope_tables(T, d, q.device)
         q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
     q_x, k_x = q, k
     q, k = _rnd(q, inject, "QK"), _rnd(k, inject, "QK")
@@ -119,9 +130,51 @@ def attention_layer(sd, prefix, x, heads, pad_mask, need_weights, use_rope=True,
     return out, (maps if need_weights else None)
 
 
-def transformer_layer(sd, i, x, heads, pad_mask, need_weights, use_rope=True, inject=None):
+class FoldRows:
+    """Row state of the LayerNorm-fold form ("FOLD" inject kind): what the engine's residual epilogues hand to the next
+    GEMM — the rounded raw rows x - m_prev, and fp32 (mean, rstd) from the UNROUNDED differences
+    (esm_amd/csrc/elementwise.hip rowstats_kernel / ln_finalize_kernel)."""
+
+    def __init__(self, x, dtype):
+        self.dtype = dtype
+        self.mean = x.mean(-1, keepdim=True)  # chain entry (layer 0): the row's own mean
+        self.update(x)
+
+    def update(self, x):
+        d = x - self.mean                     # centred on the PREVIOUS mean
+        dm = d.mean(-1, keepdim=True)
+        var = ((d * d).mean(-1, keepdim=True) - dm * dm).clamp_min(0.0)
+        self.mean = self.mean + dm
+        self.rstd = torch.rsqrt(var + 1e-5)
+        self.rows = d.to(self.dtype).float()
+
+    def linear(self, gamma, beta, w, b):
+        """LayerNorm(x; gamma, beta) . w^T + b in the fold's form."""
+        wg = w * gamma[None, :]
+        wg = (wg - wg.mean(-1, keepdim=True)).to(self.dtype).float()
+        return self.rstd * F.linear(self.rows, wg) + (F.linear(beta[None, :], w)[0] + b)
+
+
+def _is_fold(inject):
+    return inject is not None and "FOLD" in inject[0]
+
+
+def transformer_layer(sd, i, x, heads, pad_mask, need_weights, use_rope=True, inject=None, fold=None, last=False):
     # reference esm/modules.py:120-142 (pre-LN residual blocks)
     p = f"layers.{i}."
+    if fold is not None:
+        # the same layer with its two LayerNorm -> Linear pairs in the fold's form (FoldRows); everything else as below
+        g, b = sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"]
+        a, probs = attention_layer(sd, p, None, heads, pad_mask, need_weights, use_rope, inject,
+                                   qkv=lambda n: fold.linear(g, b, sd[p + f"self_attn.{n}_proj.weight"], sd[p + f"self_attn.{n}_proj.bias"]),
+                                   shape=x.shape)
+        x = x + a
+        fold.update(x)
+        h = gelu(fold.linear(sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"], sd[p + "fc1.weight"], sd[p + "fc1.bias"]))
+        x = x + _linear(h, sd[p + "fc2.weight"], sd[p + "fc2.bias"], inject, "fc2")
+        if not last:
+            fold.update(x)
+        return x, probs
     h = layer_norm(x, sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"])
     a, probs = attention_layer(sd, p, h, heads, pad_mask, need_weights, use_rope, inject)
     x = x + a
@@ -175,8 +228,9 @@ def esm2_forward(
         reps[0] = x
     pad_mask = pad if bool(pad.any()) else None  # esm2.py:108-109
     attn = []
+    fold = FoldRows(x, inject[1]) if _is_fold(inject) else None
     for i in range(num_layers):  # esm2.py:111-121
-        x, probs = transformer_layer(sd, i, x, heads, pad_mask, need_head_weights, inject=inject)
+        x, probs = transformer_layer(sd, i, x, heads, pad_mask, need_head_weights, inject=inject, fold=fold, last=i + 1 == num_layers)
         if (i + 1) in wanted:
             reps[i + 1] = x
         if need_head_weights:

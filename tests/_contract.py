@@ -14,9 +14,17 @@ r4_parity_budget_study.log).  Hence:
                                                    (plain fp16 operands do NOT reach 1e-3 there and the tests say so;
                                                    ESM_AMD_OPERAND=f16x2 does for representations and logits)
 
-SLACK = 1.25: two realisations of "the maximum of the same noise over the tensor" (engine vs emulation: different
-summation orders, fused vs separate roundings) differ by up to ~15 % on the committed fixtures; a real defect — one
-un-normalised row, a missed mask, a wrong rounding point — shows as 2 x or more, and in L2.
+The floor is computed IN THE ENGINE'S OWN FORM: with the LayerNorm fold active (the default) the oracle's "FOLD" injection
+rounds what the fold rounds (raw rows centred on the previous mean, gamma-folded row-centred weights); in the plain mode the
+plain injection.  The two forms have the same number of roundings and the same expected error, but ONE model's weight-rounding
+error acts on the row-independent part of its activations (91 % of the energy of the synthetic models' outputs) as a fixed
+bias — one draw per (weights, form): fold / plain logits L2 = 1.24 on the 650M test weights, 0.98 on the next seed, 0.92 at
+3B (profiles/r6_ln_fold_logits_study.log).  Round 5's single plain-form floor with a 1.25 slack hid that; per-form floors
+let the L2 slack go to 1.10.
+
+SLACK_L2 = 1.10, SLACK (max norm) = 1.25: two realisations of "the maximum of the same noise over the tensor" (engine vs
+emulation: different summation orders, fused vs separate roundings) differ by up to ~15 % on the committed fixtures; in L2
+by a few per cent; a real defect — one un-normalised row, a missed mask, a wrong rounding point — shows as 2 x or more, and in L2.
 Contact logits get CONTACT_SLACK = 1.5: their figure is ONE number per map — the largest logit error over ~10^5 pairs
 relative to the logit range — and logits of near-saturated probabilities are heavy-tailed, so two realisations of that maximum
 differ more: engine / floor measured 0.64 ... 1.28 over the five full-size maps in the two engine modes (fold / plain,
@@ -29,7 +37,8 @@ import os
 import torch
 
 CONTRACT = 1e-3
-SLACK = 1.25
+SLACK = 1.25      # max norm
+SLACK_L2 = 1.10   # L2 norm
 CONTACT_SLACK = 1.5
 _FLOORS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "operand_floors.json")
 
@@ -43,35 +52,73 @@ def errors(got, ref, mask=None):
     return (d.norm() / ref.norm().clamp_min(1e-30)).item(), (d.abs().max() / ref.abs().max().clamp_min(1e-30)).item()
 
 
-def floor_forward(sd, toks, L, H, dtype=torch.float16, **kw):
-    """The oracle with `dtype` rounding injected at every MFMA operand: the floor on these inputs."""
-    from oracle.esm2_oracle import ALL_OPERANDS, esm2_forward
+def fold_of(model):
+    """Does this model's engine run the LayerNorm fold?  (esm_amd.esm2.ESM2.ln_fold_active; the engine is created by the
+    first forward, so call this after one.)"""
+    active = model.ln_fold_active()
+    assert active is not None, "floor form unknown: the model has not run a forward yet"
+    return bool(active)
 
-    return esm2_forward(sd, toks, L, H, inject=(frozenset(ALL_OPERANDS), dtype), **kw)
+
+def default_fold(E, H, weight_split=False):
+    """The mode an engine created in THIS environment runs in when there is no model object to ask (a subprocess made it):
+    ESM_AMD_LN_FOLD / ESMK_LN_FOLD, else the library default (on) wherever the library supports the fold."""
+    v = os.environ.get("ESM_AMD_LN_FOLD", os.environ.get("ESMK_LN_FOLD", "1")).strip().lower()
+    return v not in ("0", "false", "off", "no") and not weight_split and E // H <= 64
 
 
-def committed_floor(case, seq=0):
-    """Floor numbers of a full-size fixture (tests/golden/make_floors.py -> operand_floors.json)."""
+def inject_kinds(fold):
+    from oracle.esm2_oracle import ALL_OPERANDS
+
+    return frozenset(ALL_OPERANDS + (("FOLD",) if fold else ()))
+
+
+def floor_forward(sd, toks, L, H, dtype=torch.float16, model=None, fold=False, forward=None, **kw):
+    """The oracle with `dtype` rounding injected at every MFMA operand, in the form the engine of `model` computes in
+    (LayerNorm fold or plain; `fold=` when there is no model object): the floor on these inputs."""
+    from oracle.esm2_oracle import esm2_forward
+
+    if model is not None:
+        fold = fold_of(model)
+    return (forward or esm2_forward)(sd, toks, L, H, inject=(inject_kinds(fold), dtype), **kw)
+
+
+def committed_floor(case, seq=0, fold=False):
+    """Floor numbers of a full-size fixture (tests/golden/make_floors.py -> operand_floors.json), in the engine's form."""
     with open(_FLOORS) as f:
-        return json.load(f)[case][seq]
+        return json.load(f)[case + ("@fold" if fold else "")][seq]
 
 
-def check(name, l2, mx, floor_l2, floor_mx, hard_l2=False, slack=SLACK):
+def raw_argmax_agreement(logits, ref_logits, mask=None):
+    a, b = logits.float().cpu().argmax(-1), ref_logits.float().cpu().argmax(-1)
+    if mask is not None:
+        a, b = a[mask], b[mask]
+    return (a == b).double().mean().item()
+
+
+def check_raw_argmax(name, raw, floor_raw, margin=5e-4):
+    """Raw token-argmax agreement with the fp32 reference must not be below what the floor itself reaches on the same
+    inputs (near-ties flip under ANY fp16-operand engine) minus 0.05 %."""
+    print(f"\ncontract {name}: raw argmax agreement {raw:.5f} (floor on the same inputs {floor_raw:.5f}, bound {floor_raw - margin:.5f})")
+    assert raw >= floor_raw - margin, (name, raw, floor_raw)
+
+
+def check(name, l2, mx, floor_l2, floor_mx, hard_l2=False, slack=SLACK, slack_l2=SLACK_L2):
     """Assert the contract on measured (l2, mx) given the floor's numbers on the same inputs; prints one line that the
-    evidence scripts grep ("contract ...")."""
-    b_l2 = CONTRACT if hard_l2 else max(CONTRACT, slack * floor_l2)
+    evidence scripts grep ("contract ...", on a line of its own: pytest -s glues its progress dots to a test's first print)."""
+    b_l2 = CONTRACT if hard_l2 else max(CONTRACT, slack_l2 * floor_l2)
     b_mx = max(CONTRACT, slack * floor_mx)
-    print(f"contract {name}: L2 {l2:.2e} (floor {floor_l2:.2e}, bound {b_l2:.2e}{' hard' if hard_l2 else ''}), "
+    print(f"\ncontract {name}: L2 {l2:.2e} (floor {floor_l2:.2e}, bound {b_l2:.2e}{' hard' if hard_l2 else ''}), "
           f"max {mx:.2e} (floor {floor_mx:.2e}, x{mx / max(floor_mx, 1e-30):.2f}, bound {b_mx:.2e})")
     assert l2 <= b_l2, (name, "L2", l2, b_l2)
     assert mx <= b_mx, (name, "max norm", mx, b_mx, floor_mx)
     return l2, mx
 
 
-def check_tensors(name, got, ref, floor, mask=None, hard_l2=False, slack=SLACK):
+def check_tensors(name, got, ref, floor, mask=None, hard_l2=False, slack=SLACK, slack_l2=SLACK_L2):
     l2, mx = errors(got, ref, mask)
     f_l2, f_mx = errors(floor, ref, mask)
-    return check(name, l2, mx, f_l2, f_mx, hard_l2=hard_l2, slack=slack)
+    return check(name, l2, mx, f_l2, f_mx, hard_l2=hard_l2, slack=slack, slack_l2=slack_l2)
 
 
 def contact_logit_errors(c, cr, sat=12.0):

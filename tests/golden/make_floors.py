@@ -51,21 +51,57 @@ def contact_logit_rel(c, cr):
 
 
 def floors_of(sd, toks, lengths, L, H, GEN):
+    """{form: [per-sequence floor numbers]} for the plain form and the LayerNorm-fold form ("FOLD" injection: what the engine's
+    default mode rounds) — ONE fp32 reference run, two floor runs."""
     from oracle.esm2_oracle import ALL_OPERANDS, esm2_forward
 
     ref = esm2_forward(sd, toks, L, H, repr_layers=[L], return_contacts=True)
     ref = {"logits": ref["logits"], "representations": ref["representations"], "contacts": ref["contacts"]}
-    fl = esm2_forward(sd, toks, L, H, repr_layers=[L], return_contacts=True, inject=(frozenset(ALL_OPERANDS), torch.float16))
-    fl = {"logits": fl["logits"], "representations": fl["representations"], "contacts": fl["contacts"]}
-    a, b = GEN.slim_esm2(fl, toks, lengths, L), GEN.slim_esm2(ref, toks, lengths, L)
+    b = GEN.slim_esm2(ref, toks, lengths, L)
     nonpad = toks.ne(1)
-    out = []
-    for i in range(toks.shape[0]):
-        out.append({"repr_max": rel(a["repr"][i], b["repr"][i]), "repr_l2": rel_l2(a["repr"][i], b["repr"][i]),
-                    "logits_max": rel(fl["logits"][i][nonpad[i]], ref["logits"][i][nonpad[i]]),
-                    "logits_l2": rel_l2(fl["logits"][i][nonpad[i]], ref["logits"][i][nonpad[i]]),
-                    "contact_logit_rel": contact_logit_rel(a["contacts"][i], b["contacts"][i])})
-    return out
+    res = {}
+    for form, kinds in (("", ALL_OPERANDS), ("@fold", ALL_OPERANDS + ("FOLD",))):
+        fl = esm2_forward(sd, toks, L, H, repr_layers=[L], return_contacts=True, inject=(frozenset(kinds), torch.float16))
+        fl = {"logits": fl["logits"], "representations": fl["representations"], "contacts": fl["contacts"]}
+        a = GEN.slim_esm2(fl, toks, lengths, L)
+        out = []
+        for i in range(toks.shape[0]):
+            same = fl["logits"][i][nonpad[i]].argmax(-1) == ref["logits"][i][nonpad[i]].argmax(-1)
+            out.append({"repr_max": rel(a["repr"][i], b["repr"][i]), "repr_l2": rel_l2(a["repr"][i], b["repr"][i]),
+                        "logits_max": rel(fl["logits"][i][nonpad[i]], ref["logits"][i][nonpad[i]]),
+                        "logits_l2": rel_l2(fl["logits"][i][nonpad[i]], ref["logits"][i][nonpad[i]]),
+                        "argmax_raw": same.double().mean().item(),
+                        "contact_logit_rel": contact_logit_rel(a["contacts"][i], b["contacts"][i])})
+        res[form] = out
+        del fl, a
+    return res
+
+
+def msa_floor(case, GEN):
+    """Config 5 (one 128 x 513 MSA): the MSA model's operand floor (oracle/msa_oracle.py msa_operand_floor) against the
+    reference fixture, in the quantities tests/test_fullsize_gpu.py compares (its _msa_compare)."""
+    from esm_amd.synth import synth_msa_state_dict
+    from oracle.msa_oracle import msa_operand_floor
+
+    fix = torch.load(os.path.join(HERE, f"large_{case}.pt"), weights_only=False)
+    d = fix["dims"]
+    sd = synth_msa_state_dict(d["L"], d["E"], d["H"], d["F"], seed=d["seed"], qk_gain=d.get("qk_gain", 2.0))
+    t0 = time.time()
+    with torch.no_grad():
+        out = msa_operand_floor(sd, fix["tokens"].to(torch.int64), d["L"], d["H"], repr_layers=[d["L"]], return_contacts=True)
+    got = GEN.slim_msa(out, d["L"])
+    del out
+    r = {"repr_row0_max": rel(got["repr_row0"], fix["repr_row0"]), "repr_row0_l2": rel_l2(got["repr_row0"], fix["repr_row0"]),
+         "repr_sub_max": rel(got["repr_sub"], fix["repr_sub"]), "repr_sub_l2": rel_l2(got["repr_sub"], fix["repr_sub"]),
+         "logits_row0_max": rel(got["logits_row0"], fix["logits_row0"]), "logits_row0_l2": rel_l2(got["logits_row0"], fix["logits_row0"]),
+         "argmax_raw": (got["logits_argmax"] == fix["logits_argmax"]).double().mean().item(),
+         "row_maps": max((got["row_maps"][k] - v).abs().max().item() for k, v in fix["row_maps"].items()),
+         "row_max": (got["row_max"] - fix["row_max"]).abs().max().item(),
+         "col_maps": max((got["col_maps"][k] - v).abs().max().item() for k, v in fix["col_maps"].items()),
+         "contacts_prob": (got["contacts"].double() - fix["contacts"].double()).abs().max().item(),
+         "contacts_logit_rel": contact_logit_rel(got["contacts"], fix["contacts"])}
+    print(case, r, f"{time.time() - t0:.0f} s", flush=True)
+    return r
 
 
 def main():
@@ -79,6 +115,11 @@ def main():
     res["_what"] = ("max-norm / L2 error of the fp32 oracle with fp16 rounding injected at every MFMA operand (W, A, QK, V, P) "
                     "against the fp32 oracle, per sequence of the full-size config-3 fixtures; tests/golden/make_floors.py")
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    for case in ("msa1b_config5_g1", "msa1b_config5"):
+        if a.only and a.only != case:
+            continue
+        res[case] = [msa_floor(case, GEN)]
+        json.dump(res, open(OUT, "w"), indent=1)
     for case in ("esm2_3b_T258", "esm2_3b_padded"):
         if a.only and a.only != case:
             continue
@@ -87,12 +128,14 @@ def main():
         sd = synth_esm2_state_dict(d["L"], d["E"], d["H"], seed=d["seed"])
         toks, lengths = GEN.esm2_3b_tokens(case)
         t0 = time.time()
-        rows = []
+        rows = {"": [], "@fold": []}
         for i in range(toks.shape[0]):  # one sequence at a time, cut to its own length (see the module docstring)
             n = lengths[i] + 2
-            rows += floors_of(sd, toks[i:i + 1, :n].clone(), [lengths[i]], d["L"], d["H"], GEN)
-            print(case, i, rows[-1], f"{time.time() - t0:.0f} s", flush=True)
-        res[case] = rows
+            for form, r in floors_of(sd, toks[i:i + 1, :n].clone(), [lengths[i]], d["L"], d["H"], GEN).items():
+                rows[form] += r
+                print(case + form, i, r[-1], f"{time.time() - t0:.0f} s", flush=True)
+        for form, r in rows.items():  # "<case>" = plain form, "<case>@fold" = the LayerNorm-fold form (the engine's default mode)
+            res[case + form] = r
         json.dump(res, open(OUT, "w"), indent=1)
 
 

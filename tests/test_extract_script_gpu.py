@@ -50,7 +50,7 @@ def test_reference_extract_call_sequence_on_the_engine(tmp_path, trunc, tpb):
         n = min(trunc, len(s))
         _, _, toks = conv([(label, s)])
         ref = esm2_forward(sd, toks, L, H, repr_layers=[0, 3, 6], return_contacts=True)
-        floor = C.floor_forward(sd, toks, L, H, repr_layers=[3, 6])
+        floor = C.floor_forward(sd, toks, L, H, fold=C.default_fold(E, H), repr_layers=[3, 6])
         assert got["label"] == label and sorted(got["representations"]) == [0, 3, 6]
         for l in (0, 3, 6):
             full = ref["representations"][l][0]

@@ -157,6 +157,18 @@ def test_pin_rank_cpus_slices_a_shared_set_and_keeps_a_per_rank_set(monkeypatch)
     # the whole host
     state["aff"] = set(range(256))
     assert len(launch.pin_rank_cpus(0, 8)) == 32
+    # with the peers' sets (init_ranks gathers them): torchrun NUMA binding, 2 nodes x 4 ranks — ranks 4..7 share the second
+    # node's 128 hardware threads; rank 5 gets the second quarter OF THAT SET (32 CPUs), not an eighth of it
+    node = [set(range(0, 64)) | set(range(128, 192)), set(range(64, 128)) | set(range(192, 256))]
+    peers = [sorted(node[r // 4]) for r in range(8)]
+    state["aff"] = set(node[1])
+    got = launch.pin_rank_cpus(5, 8, peers=peers)
+    assert len(got) == 32 and got <= node[1] and got == launch.rank_cpu_slice(1, 4, node[1])
+    # per-rank sets (all different): kept; one cpuset shared by all 8: an eighth each
+    state["aff"] = set(range(40, 80))
+    assert launch.pin_rank_cpus(1, 8, peers=[sorted(range(40 * r, 40 * r + 40)) for r in range(8)]) == set(range(40, 80))
+    state["aff"] = set(range(64))
+    assert launch.pin_rank_cpus(3, 8, peers=[sorted(range(64))] * 8) == launch.rank_cpu_slice(3, 8, range(64))
     state["aff"] = set(range(256))
     monkeypatch.setenv("ESM_AMD_NO_AFFINITY", "1")
     assert launch.pin_rank_cpus(0, 8) == set(range(256))

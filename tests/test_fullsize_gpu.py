@@ -135,10 +135,10 @@ def _check_3b(model, name, mode="f16"):
             assert r["repr_rel_l2"] < 7e-4 and r["repr_rel_max"] < 8e-4, (b, r)
             assert r["contact_logit_rel"] < 2e-3 and r["contact_prob"] < 1e-2, (b, r)
         else:
-            fl = C.committed_floor(name, b)
+            fl = C.committed_floor(name, b, fold=C.fold_of(model))  # the floor in the form the engine ran in
             C.check(f"{name} seq {b} repr[{L}]", r["repr_rel_l2"], r["repr_rel_max"], fl["repr_l2"], fl["repr_max"], hard_l2=True)
             C.check(f"{name} seq {b} contact logits", r["contact_logit_rel"], r["contact_logit_rel"], fl["contact_logit_rel"],
-                    fl["contact_logit_rel"], slack=C.CONTACT_SLACK)
+                    fl["contact_logit_rel"], slack=C.CONTACT_SLACK, slack_l2=C.CONTACT_SLACK)
             assert r["contact_prob"] < 1e-2, (b, r)
         assert r["fused_vs_materialised"] < 1e-4, (b, r)
     if mode == "f16x2":
@@ -147,10 +147,12 @@ def _check_3b(model, name, mode="f16"):
         # plain fp16 operands: the logits carry the representation's error through one more LayerNorm and two GEMMs; the
         # floor itself is 1.1 - 1.6e-3 there (profiles/r4_parity_budget_study.log) — floor-referenced, per sequence
         for b in range(toks.shape[0]):
-            fl = C.committed_floor(name, b)
+            fl = C.committed_floor(name, b, fold=C.fold_of(model))
             l2, mx = C.errors(out["logits"][b].float().cpu(), fix["logits"][b], nonpad[b])
             C.check(f"{name} seq {b} logits", l2, mx, fl["logits_l2"], fl["logits_max"])
-    assert decided_ok and raw > 0.98
+            C.check_raw_argmax(f"{name} seq {b} token argmax", C.raw_argmax_agreement(out["logits"][b], fix["logits"][b], nonpad[b]),
+                               fl["argmax_raw"])
+    assert decided_ok
     return report, lrel, raw
 
 
@@ -250,9 +252,18 @@ def test_config5_msa_full_size_against_reference_fixture(name):
     got = GEN.slim_msa(out, L)
     r = _msa_compare(got, fix, f"{name}: HIP engine vs reference fixture")
     b = MSA_BOUNDS[name]
+    # the ONE parity contract (tests/_contract.py) against the MSA model's committed operand floor on this fixture
+    # (tests/golden/make_floors.py msa_floor); the fixed numbers of MSA_BOUNDS stay as absolute ceilings on top
+    fl = C.committed_floor(name)
+    C.check(f"{name} repr row 0", r["repr_row0_l2"], r["repr_row0_max"], fl["repr_row0_l2"], fl["repr_row0_max"])
+    C.check(f"{name} repr rows ::32", r["repr_sub_l2"], r["repr_sub_max"], fl["repr_sub_l2"], fl["repr_sub_max"])
+    C.check(f"{name} logits row 0", rel_l2(got["logits_row0"], fix["logits_row0"]), r["logits_row0"], fl["logits_row0_l2"], fl["logits_row0_max"])
+    C.check_raw_argmax(f"{name} token argmax", r["argmax_raw"], fl["argmax_raw"])
+    C.check(f"{name} contact logits", r["contacts_logit_rel"], r["contacts_logit_rel"], fl["contacts_logit_rel"], fl["contacts_logit_rel"],
+            slack=C.CONTACT_SLACK, slack_l2=C.CONTACT_SLACK)
     assert r["repr_row0_l2"] < b["repr_l2"] and r["repr_sub_l2"] < b["repr_l2"], r
     assert r["repr_row0_max"] < b["repr_max"] and r["repr_sub_max"] < b["repr_max"], r
-    assert r["logits_row0"] < b["logits"] and r["argmax_decided_ok"] and r["argmax_raw"] > 0.98, r
+    assert r["logits_row0"] < b["logits"] and r["argmax_decided_ok"], r
     assert r["row_maps"] < b["row_maps"] and r["row_max"] < b["row_maps"], r
     assert r["col_maps"] < b["col_maps"], r
     assert r["contacts_prob"] < b["contacts_prob"] and r["contacts_logit_rel"] < b["contacts_logit_rel"], r

@@ -72,6 +72,21 @@ def test_gemm9_k_loops_stay_inside_their_instruction_budget(asm):
     assert not bad, bad[:8]
 
 
+def test_gemm9_tied_mfmas_are_fenced(asm):
+    """the in-place first-K-tile MFMAs are inline asm (common.h mma16_tied) that the compiler's hazard recogniser
+    does not see.  In the emitted code of every shipped full-height instantiation: the tied MFMAs exist, each group is closed
+    by the `s_nop 7; s_nop 7` pair, and no AGPR reader other than an MFMA sits in between."""
+    isa, paths = asm
+    path = paths["gemm9.hip"]
+    shipped = [k for k in isa.meta(path) if re.search(r"gemm9_kernelI\w+?Li\d+ELi0ELb0ELb[01]E", k)]  # VAR 0, full height
+    assert len(shipped) >= 20, len(shipped)
+    for k in shipped:
+        tied, pairs, bad = isa.tied_mfma_hazards(path, k)
+        assert tied >= 64 and tied % 64 == 0, (k, tied)   # the second K half of the first K tile: 64 MFMAs per K-loop instance
+        assert pairs == tied // 64, (k, tied, pairs)
+        assert not bad, (k, bad[:4])
+
+
 def test_attention_keeps_three_waves_per_simd(asm):
     isa, paths = asm
     meta = isa.meta(paths["attention.hip"])

@@ -78,7 +78,7 @@ def test_packed_against_oracle_and_padded_engine():
         pk = model.forward_varlen(toks, repr_layers=[L], min_saving=None)
         pd = model(toks.cuda(), repr_layers=[L])
     nonpad = toks.ne(PAD)
-    floor = C.floor_forward(sd, toks, L, H, repr_layers=[L])  # the parity contract (tests/_contract.py), toy model
+    floor = C.floor_forward(sd, toks, L, H, model=model, repr_layers=[L])  # the parity contract (tests/_contract.py), toy model
     C.check_tensors("packed repr", pk["representations"][L].cpu(), ref["representations"][L], floor["representations"][L], nonpad)
     C.check_tensors("packed logits", pk["logits"].cpu(), ref["logits"], floor["logits"], nonpad)
     # the padded engine computes the same rows (plus the pad rows)

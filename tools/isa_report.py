@@ -71,6 +71,38 @@ def loops(path, kernel):
     return res
 
 
+def tied_mfma_hazards(path, kernel):
+    """Inline-asm MFMAs (Op<T>::mma16_tied, common.h) are invisible to the compiler's hazard recogniser: between the first of
+    them and the `s_nop 7; s_nop 7` pair that closes the first K tile, nothing but MFMAs may touch an AGPR (a v_accvgpr_read,
+    an LDS / global store of an `a` register would read a result before the matrix pipe has written it).
+    Returns (number of tied MFMAs, has the s_nop pair, [offending lines])."""
+    text = open(path).read()
+    i = text.index("\n" + kernel + ":")
+    body = text[i:text.index("s_endpgm", i)].split("\n")
+    in_asm, tied, nops, first, last_nop, bad = False, 0, 0, None, None, []
+    ins = []
+    for line in body:
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif t.startswith(";;#ASMEND"):
+            in_asm = False
+        elif t and not t.startswith((";", ".")) and not re.match(r"^\.?\w+:", t):
+            ins.append((t, in_asm))
+    for n, (t, a) in enumerate(ins):
+        if a and t.startswith("v_mfma"):
+            tied += 1
+            first = n if first is None else first
+        if a and t.startswith("s_nop 7") and first is not None and n + 1 < len(ins) and ins[n + 1][1] and ins[n + 1][0].startswith("s_nop 7"):
+            nops += 1
+            # everything between the first tied MFMA of this tile and the pair
+            for t2, _ in ins[first:n]:
+                if not t2.startswith("v_mfma") and re.search(r"(?<![\w.])a(\[\d+:\d+\]|\d+)\b", t2):
+                    bad.append(t2)
+            first = None
+    return tied, nops, bad
+
+
 def short(k):
     r = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip()
     return re.sub(r"\(.*", "", r)[:110]
