@@ -278,7 +278,7 @@ def run_esm2_650m(args, dist, rank, world, dev):
     MODEL = "esm2_t33_650M_UR50D"
     FLOP_PER_RESIDUE = 1.4769e9  # SURVEY.md §8 d: 1.509 TFLOP per 1024-token sequence / 1022 residues
     L, E, H = ESM2_DIMS[MODEL]
-    sd = synth_esm2_state_dict(L, E, H, seed=0)          # identical replica on every rank
+    sd = synth_esm2_state_dict(L, E, H, seed=0, qk_gain=args.qk_gain, ln_gamma_std=args.ln_gamma_std)  # identical replica on every rank
     with skip_param_init():
         model = esm.ESM2(L, E, H).eval()
     model.load_state_dict(sd)
@@ -332,7 +332,8 @@ def run_esm2_650m(args, dist, rank, world, dev):
     result = base_result(
         args, world, "residues/sec (whole node) ESM-2 650M L=1022 bulk extract", value, elapsed,
         f"{MODEL} forward (repr_layers=[33] + logits), synthetic tokens [B,{args.seq_len + 2}], random-init weights "
-        "of the 650M architecture", {"batch_per_gpu": batch, "seq_len": args.seq_len}, model)
+        "of the 650M architecture", {"batch_per_gpu": batch, "seq_len": args.seq_len,
+                                     "synthetic_weights": {"qk_gain": args.qk_gain, "ln_gamma_std": args.ln_gamma_std}}, model)
     build = library_build()
     fold_on = model.ln_fold_active()
     traffic = lambda cls: pmc_traffic(cls, build["src_hash"], "esm2_650m", batch, fold_on)
@@ -375,7 +376,27 @@ def run_esm2_650m(args, dist, rank, world, dev):
                                 "reference": "fp32 oracle outputs of the parent run on the same 4 sequences"}
         except Exception as e:
             result["parity"] = {"error": f"{type(e).__name__}: {e}"[:200]}
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.quick_baseline:
+        # a secondary line's own bounded sample: ONE sequence of the timed batch through the fp32 oracle (+ the operand floor)
+        from oracle.esm2_oracle import esm2_forward
+
+        ncores = cpu_threads()
+        s1 = toks[:1].cpu()
+        c0 = time.perf_counter()
+        ref = esm2_forward(sd, s1, L, H, repr_layers=[L])
+        t1 = time.perf_counter() - c0
+        with torch.no_grad():
+            got = model(toks[:1], repr_layers=[L])
+        r_gpu, r_ref = got["representations"][L].cpu().double(), ref["representations"][L].double()
+        max_abs = (r_gpu - r_ref).abs().max().item()
+        result["cpu_baseline"] = {"value": round(args.seq_len / t1, 1), "unit": "residues/s", "cores": torch.get_num_threads(),
+                                  "host_cores": os.cpu_count(), "kind": "port",
+                                  "sample": f"fp32 oracle on {ncores} threads: 1 sequence of the timed batch (L={args.seq_len}), 1 forward, cold"}
+        result["parity"] = {"max_abs_repr_diff_vs_cpu": max_abs, "rel_repr_diff_vs_cpu": max_abs / r_ref.abs().max().item(),
+                            "rel_l2_repr_diff_vs_cpu": ((r_gpu - r_ref).norm() / r_ref.norm()).item(),
+                            **argmax_report(got["logits"].float().cpu(), ref["logits"].float()), "sample_sequences": 1}
+        result["parity"]["operand_floor_same_inputs"] = operand_floor_report(sd, s1, L, H, r_ref, ref["logits"], fold=bool(model.ln_fold_active()))
+    elif world == 1 and not args.no_cpu_baseline:
         from oracle.esm2_oracle import esm2_forward
 
         ncores = cpu_threads()
@@ -466,6 +487,11 @@ SECONDARY = [  # --quick-baseline: the children's own CPU-oracle sample (parity 
                       "--parity-ref", "{PARITY_REF}"], 60),
     ("esm2_650m_b4_plain", ["--workload", "esm2_650m", "--batch", "4", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
                             "--no-secondary", "--ln-fold", "0", "--parity-ref", "{PARITY_REF}"], 60),
+    # data sensitivity: under the power cap the rates depend on the operand statistics — the headline
+    # configuration once more on synthetic weights with sharper attention (qk_gain 4) and wider LayerNorm gains (std 0.1),
+    # with its own parity sample
+    ("esm2_650m_sharp", ["--workload", "esm2_650m", "--steps", "10", "--warmup", "3", "--no-secondary", "--quick-baseline",
+                         "--qk-gain", "4", "--ln-gamma-std", "0.1"], 90),
 ]
 T_PROCESS_START = time.perf_counter()
 SECONDARY_BUDGET_S = 230.0  # the default run, children included, ends within ~4 minutes of its start
@@ -824,6 +850,8 @@ def main():
                     help="MFMA operand type (default f16; bf16 is ~4 %% faster at ~7e-3 relative error; f16x2 = fp16 with "
                          "split weights W = W_hi + W_lo: 2x GEMM time, ~40 %% lower error — the precision mode with "
                          "margin under the 1e-3 contract).  Sets ESM_AMD_OPERAND for this run.")
+    ap.add_argument("--qk-gain", type=float, default=2.0, help="esm2_650m: gain of the synthetic q / k projection weights (default 2)")
+    ap.add_argument("--ln-gamma-std", type=float, default=0.02, help="esm2_650m: spread of the synthetic LayerNorm gains (default 0.02)")
     ap.add_argument("--parity-ref", default="", help="esm2_650m: file with {tokens, repr, logits} of the fp32 oracle on 4 sample "
                                                        "sequences (written by the default run for its secondary lines): report "
                                                        "`parity` of this configuration against it")

@@ -82,8 +82,9 @@ def _draw(key, shape, seed, std, mean=0.0, device="cpu"):
     return torch.randn(shape, generator=g, device=device, dtype=torch.float32) * std + mean
 
 
-def synth_esm2_state_dict(num_layers, embed_dim, heads, seed=0, qk_gain=2.0, device="cpu", vocab=33):
-    """fp32 state dict with the reference's key names (tied lm_head.weight included)."""
+def synth_esm2_state_dict(num_layers, embed_dim, heads, seed=0, qk_gain=2.0, device="cpu", vocab=33, ln_gamma_std=0.02):
+    """fp32 state dict with the reference's key names (tied lm_head.weight included).  ``qk_gain`` / ``ln_gamma_std``: the
+    two knobs of the data-sensitivity line of bench.py (sharper attention maps, wider spread of the LayerNorm gains)."""
     sd = {}
     d = embed_dim // heads
     for key, shape in esm2_param_shapes(num_layers, embed_dim, heads, vocab).items():
@@ -98,7 +99,7 @@ def synth_esm2_state_dict(num_layers, embed_dim, heads, seed=0, qk_gain=2.0, dev
         elif key.startswith("contact_head.regression.bias"):
             sd[key] = _draw(key, shape, seed, 0.5, mean=-1.0, device=device)
         elif "layer_norm" in key and key.endswith(".weight"):
-            sd[key] = _draw(key, shape, seed, 0.02, mean=1.0, device=device)
+            sd[key] = _draw(key, shape, seed, ln_gamma_std, mean=1.0, device=device)
         elif len(shape) == 2:
             # std 0.02 at fan-in 1280, scaled with fan-in^-1/2 so that activation statistics (and
             # the sharpness of the attention) do not depend on the model width

@@ -22,13 +22,16 @@ bias — one draw per (weights, form): fold / plain logits L2 = 1.24 on the 650M
 3B (profiles/r6_ln_fold_logits_study.log).  Round 5's single plain-form floor with a 1.25 slack hid that; per-form floors
 let the L2 slack go to 1.10.
 
-SLACK_L2 = 1.10, SLACK (max norm) = 1.25: two realisations of "the maximum of the same noise over the tensor" (engine vs
-emulation: different summation orders, fused vs separate roundings) differ by up to ~15 % on the committed fixtures; in L2
-by a few per cent; a real defect — one un-normalised row, a missed mask, a wrong rounding point — shows as 2 x or more, and in L2.
-Contact logits get CONTACT_SLACK = 1.5: their figure is ONE number per map — the largest logit error over ~10^5 pairs
-relative to the logit range — and logits of near-saturated probabilities are heavy-tailed, so two realisations of that maximum
-differ more: engine / floor measured 0.64 ... 1.28 over the five full-size maps in the two engine modes (fold / plain,
-profiles/r5_gpu_tests_contract_lines.txt, r5_gpu_tests_plain_mode.txt).
+SLACK_L2 = 1.10, SLACK (max norm) = 1.25 (1.35 on few-layer toy models): measured over the 133 contract lines of the whole
+`-m gpu` suite, engine / floor-in-its-own-form (profiles/r6_gpu_tests_contract_lines*.txt): in L2 median 0.998, largest 1.066
+(fold mode) / 1.060 (plain mode) — the L2 bound is the one that sees a defect (an un-normalised row, a missed mask, a wrong
+rounding point shows as 2 x or more, and in L2); in the max norm median 0.98, the four largest 1.19, 1.23, 1.24, 1.27 — two
+realisations of "the maximum of the same noise over the tensor" (different summation orders, fused vs separate roundings),
+all four on toy fixtures of 2 - 6 layers with 10^4 - 10^5 elements; every >= 30-layer configuration is inside 1.15.
+Contact logits get CONTACT_SLACK = 1.3 (1.5 in round 5): their figure is ONE number per map — the largest logit error over
+~10^5 pairs relative to the logit range — and logits of near-saturated probabilities are heavy-tailed.  Against the floor in
+the engine's own form, engine / floor over the nine full-size and 3B-dims maps: 0.89 ... 1.05 in the fold mode (the
+default), 0.85 ... 1.27 in the plain mode (profiles/r6_gpu_tests_contract_lines*.txt).
 Integer outputs (tokens, argmax wherever the reference's top-2 margin exceeds twice the logit error) are exact.
 """
 import json
@@ -38,8 +41,9 @@ import torch
 
 CONTRACT = 1e-3
 SLACK = 1.25      # max norm
+SLACK_TOY = 1.35  # max norm on few-layer toy models (the same statistic over 10^4 - 10^5 elements: see above)
 SLACK_L2 = 1.10   # L2 norm
-CONTACT_SLACK = 1.5
+CONTACT_SLACK = 1.3
 _FLOORS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "operand_floors.json")
 
 
@@ -103,9 +107,11 @@ def check_raw_argmax(name, raw, floor_raw, margin=5e-4):
     assert raw >= floor_raw - margin, (name, raw, floor_raw)
 
 
-def check(name, l2, mx, floor_l2, floor_mx, hard_l2=False, slack=SLACK, slack_l2=SLACK_L2):
+def check(name, l2, mx, floor_l2, floor_mx, hard_l2=False, slack=None, slack_l2=SLACK_L2, deep=None):
     """Assert the contract on measured (l2, mx) given the floor's numbers on the same inputs; prints one line that the
     evidence scripts grep ("contract ...", on a line of its own: pytest -s glues its progress dots to a test's first print)."""
+    if slack is None:  # deep = the full-size configurations (BASELINE's models / fixtures); hard_l2 implies it
+        slack = SLACK if (hard_l2 if deep is None else deep) else SLACK_TOY
     b_l2 = CONTRACT if hard_l2 else max(CONTRACT, slack_l2 * floor_l2)
     b_mx = max(CONTRACT, slack * floor_mx)
     print(f"\ncontract {name}: L2 {l2:.2e} (floor {floor_l2:.2e}, bound {b_l2:.2e}{' hard' if hard_l2 else ''}), "
@@ -115,10 +121,10 @@ def check(name, l2, mx, floor_l2, floor_mx, hard_l2=False, slack=SLACK, slack_l2
     return l2, mx
 
 
-def check_tensors(name, got, ref, floor, mask=None, hard_l2=False, slack=SLACK, slack_l2=SLACK_L2):
+def check_tensors(name, got, ref, floor, mask=None, hard_l2=False, slack=None, slack_l2=SLACK_L2, deep=None):
     l2, mx = errors(got, ref, mask)
     f_l2, f_mx = errors(floor, ref, mask)
-    return check(name, l2, mx, f_l2, f_mx, hard_l2=hard_l2, slack=slack, slack_l2=slack_l2)
+    return check(name, l2, mx, f_l2, f_mx, hard_l2=hard_l2, slack=slack, slack_l2=slack_l2, deep=deep)
 
 
 def contact_logit_errors(c, cr, sat=12.0):

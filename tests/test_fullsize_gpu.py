@@ -149,7 +149,7 @@ def _check_3b(model, name, mode="f16"):
         for b in range(toks.shape[0]):
             fl = C.committed_floor(name, b, fold=C.fold_of(model))
             l2, mx = C.errors(out["logits"][b].float().cpu(), fix["logits"][b], nonpad[b])
-            C.check(f"{name} seq {b} logits", l2, mx, fl["logits_l2"], fl["logits_max"])
+            C.check(f"{name} seq {b} logits", l2, mx, fl["logits_l2"], fl["logits_max"], deep=True)
             C.check_raw_argmax(f"{name} seq {b} token argmax", C.raw_argmax_agreement(out["logits"][b], fix["logits"][b], nonpad[b]),
                                fl["argmax_raw"])
     assert decided_ok
@@ -255,9 +255,9 @@ def test_config5_msa_full_size_against_reference_fixture(name):
     # the ONE parity contract (tests/_contract.py) against the MSA model's committed operand floor on this fixture
     # (tests/golden/make_floors.py msa_floor); the fixed numbers of MSA_BOUNDS stay as absolute ceilings on top
     fl = C.committed_floor(name)
-    C.check(f"{name} repr row 0", r["repr_row0_l2"], r["repr_row0_max"], fl["repr_row0_l2"], fl["repr_row0_max"])
-    C.check(f"{name} repr rows ::32", r["repr_sub_l2"], r["repr_sub_max"], fl["repr_sub_l2"], fl["repr_sub_max"])
-    C.check(f"{name} logits row 0", rel_l2(got["logits_row0"], fix["logits_row0"]), r["logits_row0"], fl["logits_row0_l2"], fl["logits_row0_max"])
+    C.check(f"{name} repr row 0", r["repr_row0_l2"], r["repr_row0_max"], fl["repr_row0_l2"], fl["repr_row0_max"], deep=True)
+    C.check(f"{name} repr rows ::32", r["repr_sub_l2"], r["repr_sub_max"], fl["repr_sub_l2"], fl["repr_sub_max"], deep=True)
+    C.check(f"{name} logits row 0", rel_l2(got["logits_row0"], fix["logits_row0"]), r["logits_row0"], fl["logits_row0_l2"], fl["logits_row0_max"], deep=True)
     C.check_raw_argmax(f"{name} token argmax", r["argmax_raw"], fl["argmax_raw"])
     C.check(f"{name} contact logits", r["contacts_logit_rel"], r["contacts_logit_rel"], fl["contacts_logit_rel"], fl["contacts_logit_rel"],
             slack=C.CONTACT_SLACK, slack_l2=C.CONTACT_SLACK)

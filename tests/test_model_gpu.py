@@ -132,7 +132,7 @@ def test_650m_dims_against_oracle(B, T, padded):
     for l in (1, 16, 33):  # the contract: L2 <= 1e-3 hard, max norm floor-referenced
         C.check_tensors(f"650M-dims B={B} T={T} repr[{l}]", out["representations"][l].cpu(), ref["representations"][l],
                         floor["representations"][l], nonpad, hard_l2=True)
-    C.check_tensors(f"650M-dims B={B} T={T} logits", out["logits"].cpu(), ref["logits"], floor["logits"], nonpad)
+    C.check_tensors(f"650M-dims B={B} T={T} logits", out["logits"].cpu(), ref["logits"], floor["logits"], nonpad, deep=True)
     assert decided_ok
     C.check_raw_argmax(f"650M-dims B={B} T={T} token argmax", raw, C.raw_argmax_agreement(floor["logits"], ref["logits"], nonpad))
 
@@ -152,7 +152,7 @@ def test_3b_dims_contacts_against_oracle():
     c, cr, cf = out["contacts"].cpu(), ref["contacts"], floor["contacts"]
     C.check_tensors("3B-dims T=96 repr[36]", out["representations"][36].cpu(), ref["representations"][36],
                     floor["representations"][36], nonpad, hard_l2=True)
-    C.check_tensors("3B-dims T=96 logits", out["logits"].cpu(), ref["logits"], floor["logits"], nonpad)
+    C.check_tensors("3B-dims T=96 logits", out["logits"].cpu(), ref["logits"], floor["logits"], nonpad, deep=True)
     # contact logits relative to the largest unsaturated reference logit; valid region of sequence 1 is [:59,:59]
     for b, sl in ((0, slice(None)), (1, slice(0, 59))):
         perr = (c[b, sl, sl] - cr[b, sl, sl]).abs().max().item()
