@@ -158,7 +158,8 @@ def protocol_test(args):
 # ---------------------------------------------------------------------------------------------------------------
 def operand_name():
     env = os.environ.get("ESM_AMD_OPERAND", "").lower()
-    return "bf16" if env in ("bf16", "bfloat16") else "f16x2" if env in ("f16x2", "fp16x2") else "f16"
+    return ("bf16" if env in ("bf16", "bfloat16") else "f16x2" if env in ("f16x2", "fp16x2")
+            else "f16x2a" if env in ("f16x2a", "fp16x2a") else "f16")
 
 
 def library_build():
@@ -450,9 +451,13 @@ def operand_floor_report(sd, toks_cpu, L, H, r_ref, logits_ref=None, fold=False)
         from oracle.esm2_oracle import ALL_OPERANDS, esm2_forward
 
         odt = torch.bfloat16 if operand_name() == "bf16" else torch.float16
-        # f16x2 (split weights): the floor of that mode keeps the weights exact
+        # f16x2 (split weights): the floor of that mode keeps the weights exact; f16x2a: those of the attention projections;
+        # both run the LM head on the fp32 MFMA path (no rounding there)
         kinds = [k for k in ALL_OPERANDS if not (operand_name() == "f16x2" and k == "W")] + (["FOLD"] if fold else [])
-        fl = esm2_forward(sd, toks_cpu, L, H, repr_layers=[L], inject=(frozenset(kinds), odt))
+        if operand_name() == "f16x2a":
+            kinds += ["W!qk", "W!v", "W!o"]
+        head = {"inject_head": None} if operand_name() in ("f16x2", "f16x2a") else {}
+        fl = esm2_forward(sd, toks_cpu, L, H, repr_layers=[L], inject=(frozenset(kinds), odt), **head)
         lg = fl["logits"].double()
         fl = fl["representations"][L].double()
         rep = {"rel_repr_diff_vs_cpu": ((fl - r_ref).abs().max() / r_ref.abs().max()).item(),
@@ -492,6 +497,10 @@ SECONDARY = [  # --quick-baseline: the children's own CPU-oracle sample (parity 
     # with its own parity sample
     ("esm2_650m_sharp", ["--workload", "esm2_650m", "--steps", "10", "--warmup", "3", "--no-secondary", "--quick-baseline",
                          "--qk-gain", "4", "--ln-gamma-std", "0.1"], 90),
+    # precision mode f16x2a (round 6): split weights on the attention projections only — representations AND logits inside
+    # 1e-3 in both norms at ~1.3 x the plain step; same 4 sequences, same fp32 reference as the headline line
+    ("esm2_650m_f16x2a", ["--workload", "esm2_650m", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-secondary",
+                          "--operand", "f16x2a", "--parity-ref", "{PARITY_REF}"], 90),
 ]
 T_PROCESS_START = time.perf_counter()
 SECONDARY_BUDGET_S = 230.0  # the default run, children included, ends within ~4 minutes of its start
@@ -846,7 +855,7 @@ def main():
     ap.add_argument("--ln-fold", type=int, choices=[0, 1], default=None,
                     help="LayerNorm fold of the engine (esmk_config.ln_fold, DESIGN.md 4.8): 1 = the per-layer LayerNorm passes "
                          "become GEMM epilogue work (the library default since round 5: faster at every batch size), 0 = off")
-    ap.add_argument("--operand", choices=["f16", "bf16", "f16x2"], default=None,
+    ap.add_argument("--operand", choices=["f16", "bf16", "f16x2", "f16x2a"], default=None,
                     help="MFMA operand type (default f16; bf16 is ~4 %% faster at ~7e-3 relative error; f16x2 = fp16 with "
                          "split weights W = W_hi + W_lo: 2x GEMM time, ~40 %% lower error — the precision mode with "
                          "margin under the 1e-3 contract).  Sets ESM_AMD_OPERAND for this run.")

@@ -103,6 +103,11 @@ struct esmk_model {
     int unit_cap = 0;
 };
 
+// Precision modes with split weights (esmk_config::weight_split): 1 = f16x2, every matrix of the layer stack as W_hi + W_lo;
+// 2 = f16x2a, the attention projections (q, k, v, out) only — a third of the GEMM work, most of the accuracy
+static inline bool split_attn(const esmk_model* m) { return m->cfg.weight_split == 1 || m->cfg.weight_split == 2; }
+static inline bool split_ffn(const esmk_model* m) { return m->cfg.weight_split == 1; }
+
 // ---- per-kernel-class timing (esmk_profile_begin / _end): classes of both engines ---------------------------
 enum {
     PC_EMBED = 0, PC_LAYERNORM, PC_GEMM_QKV, PC_ATTENTION, PC_ATTN_PROBS, PC_GEMM_OUT, PC_GEMM_FC1,

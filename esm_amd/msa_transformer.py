@@ -74,11 +74,11 @@ class LearnedPositionalEmbedding(nn.Embedding):
 
 
 class _MsaEngine:
-    def __init__(self, model, device, operand_dtype, weight_split=False):
+    def __init__(self, model, device, operand_dtype, weight_split=0):
         from . import _native as N
 
         self.N, self.device, self.operand_dtype = N, device, operand_dtype
-        self.weight_split = bool(weight_split)  # ESM_AMD_OPERAND=f16x2 (esmk_msa_config.weight_split)
+        self.weight_split = int(weight_split)  # ESM_AMD_OPERAND=f16x2 / f16x2a (esmk_msa_config.weight_split: 1 / 2)
         a = model.args
         cfg = N.EsmkMsaConfig(
             a.layers, a.embed_dim, a.attention_heads, a.ffn_embed_dim, model.alphabet_size, model.padding_idx,

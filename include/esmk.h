@@ -70,7 +70,10 @@ typedef struct esmk_config {
     /* Precision mode "f16x2" (operand_dtype must be ESMK_F16): the weight matrices of the layer stack are kept as
      * W = W_hi + W_lo (two fp16 images, ~20 bits of every weight) and every layer GEMM runs both against the fp16
      * activations — the weight rounding, two thirds of the fp16-operand error of a 33-layer stack,
-     * disappears at 2x the GEMM time.  Parameter image 2x larger.  0 = plain fp16 / bf16 operands. */
+     * disappears at 2x the GEMM time.  Parameter image 2x larger.  0 = plain fp16 / bf16 operands.
+     * 2 = "f16x2a" (round 6): the same for the ATTENTION projections only (q, k, v, out_proj:
+     * esm/multihead_attention.py:256-261,395 — a third of the GEMM work); fc1 / fc2 stay plain fp16, the LM head runs in
+     * fp32 as with 1.  Representations and logits inside 1e-3 in both norms at ~1.3x the plain step. */
     int32_t weight_split;
     /* LayerNorm fold (reference esm/modules.py:120-140, the two LayerNorm -> Linear pairs of a TransformerLayer): 1 = the
      * q/k/v and fc1 weights are packed multiplied by the LayerNorm weight and row-centred, the residual GEMMs emit the
@@ -156,7 +159,8 @@ typedef struct esmk_msa_config {
     int32_t has_msa_position_embedding;  /* args.embed_positions_msa (msa_transformer.py:104-112) */
     int32_t operand_dtype;               /* ESMK_F16 or ESMK_BF16 */
     int32_t weight_split;                /* 1: precision mode f16x2 (see esmk_config::weight_split; operand_dtype ESMK_F16): every weight
-                                            matrix of the axial layers as W_hi + W_lo, the LM head on the fp32 MFMA path */
+                                            matrix of the axial layers as W_hi + W_lo, the LM head on the fp32 MFMA path;
+                                            2: f16x2a, the row / column attention projections only */
 } esmk_msa_config;
 
 /* Replaces MSATransformer.__init__; the handle is packed with esmk_pack_weight (MSATransformer
