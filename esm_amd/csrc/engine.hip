@@ -43,7 +43,7 @@ void plan_packed(esmk_model* m) {
     const size_t E = m->E, F = m->F, V = m->V, EA = m->EA, Kp = m->Kp;
     // f16x2: every layer matrix as [rows, 2 cols] (hi | lo K tiles); f16x2a (weight_split 2): the attention projections only
     const size_t ws = m->cfg.weight_split ? 2 : 1;
-    const size_t wsa = split_attn(m) ? 2 : 1, wsm = split_ffn(m) ? 2 : 1;
+    const SplitPlan sp = split_plan(m);
     Carve c;
     m->embed_f32 = c.take(V * E * 4);
     m->embed_op = c.take(V * Kp * os);
@@ -65,13 +65,13 @@ void plan_packed(esmk_model* m) {
     m->layer.resize(m->L);
     for (int l = 0; l < m->L; ++l) {
         LayerOff& o = m->layer[l];
-        o.wqkv = c.take(3 * EA * Kp * os * wsa);
+        o.wqkv = c.take(EA * Kp * os * (2 * sp.qk + sp.v));   // q, k rows | v rows (each block with its own row length)
         o.bqkv = c.take(3 * EA * 4);
-        o.wo = c.take(E * EA * os * wsa);
+        o.wo = c.take(E * EA * os * sp.o);
         o.bo = c.take(E * 4);
-        o.w1 = c.take(F * Kp * os * wsm);
+        o.w1 = c.take(F * Kp * os * sp.ffn);
         o.b1 = c.take(F * 4);
-        o.w2 = c.take(E * F * os * wsm);
+        o.w2 = c.take(E * F * os * sp.ffn);
         o.b2 = c.take(E * 4);
         o.ln1g = c.take(E * 4);
         o.ln1b = c.take(E * 4);
@@ -249,9 +249,9 @@ int esmk_create(const esmk_config* cfg, esmk_model** out) {
                     "heads are spread over 64 slots at pack time)");
     if (cfg->embed_dim % 8 != 0 || cfg->ffn_dim % 64 != 0)
         return fail("esmk_create: embed_dim must be a multiple of 8 and ffn_dim a multiple of 64");
-    if (cfg->weight_split < 0 || cfg->weight_split > 2) return fail("esmk_create: weight_split must be 0 (off), 1 (f16x2) or 2 (f16x2a)");
+    if (cfg->weight_split < 0 || cfg->weight_split > 3) return fail("esmk_create: weight_split must be 0 (off), 1 (f16x2), 2 (f16x2a) or 3 (f16x2v)");
     if (cfg->weight_split != 0 && cfg->operand_dtype != ESMK_F16)
-        return fail("esmk_create: weight_split (precision modes f16x2 / f16x2a) needs operand_dtype ESMK_F16");
+        return fail("esmk_create: weight_split (precision modes f16x2 / f16x2a / f16x2v) needs operand_dtype ESMK_F16");
     // LayerNorm fold: explicit request, or the library default / ESMK_LN_FOLD where the configuration supports it
     const bool fold_ok = cfg->weight_split == 0 && d <= 64;
     if (cfg->ln_fold > 0 && !fold_ok)
@@ -347,7 +347,7 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
     };
     // a matrix of the layer stack: plain operand-dtype image, or (f16x2) the hi | lo split image with rows of 2 ld
     const size_t ws = m->cfg.weight_split ? 2 : 1;
-    const size_t wsa = split_attn(m) ? 2 : 1, wsm = split_ffn(m) ? 2 : 1;  // attention projections / feed-forward matrices
+    const SplitPlan sp = split_plan(m);  // factor 2 = W_hi | W_lo image
     auto putw = [&](size_t off, size_t rows, size_t cols, size_t ld, int rmap, int cmap, size_t split = 0) -> int {
         if ((split ? split : ws) == 1) return put2d(off, op, rows, cols, ld, rmap, cmap);
         if (n != rows * cols)
@@ -376,21 +376,21 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
             if (starts_with(sub, "row_self_attention.")) { a = &o.row; sub += 19; }
             else if (starts_with(sub, "column_self_attention.")) { a = &o.col; sub += 22; }
             if (a) {
-                if (!strcmp(sub, "layer.q_proj.weight")) return putw(a->wqkv, E, E, E, 0, 0, wsa);
-                if (!strcmp(sub, "layer.k_proj.weight")) return putw(a->wqkv + E * E * os * wsa, E, E, E, 0, 0, wsa);
-                if (!strcmp(sub, "layer.v_proj.weight")) return putw(a->wqkv + 2 * E * E * os * wsa, E, E, E, 0, 0, wsa);
+                if (!strcmp(sub, "layer.q_proj.weight")) return putw(a->wqkv, E, E, E, 0, 0, sp.qk);
+                if (!strcmp(sub, "layer.k_proj.weight")) return putw(a->wqkv + E * E * os * sp.qk, E, E, E, 0, 0, sp.qk);
+                if (!strcmp(sub, "layer.v_proj.weight")) return putw(a->wqkv + 2 * E * E * os * sp.qk, E, E, E, 0, 0, sp.v);
                 if (!strcmp(sub, "layer.q_proj.bias")) return put(a->bqkv, ESMK_DT_F32, E);
                 if (!strcmp(sub, "layer.k_proj.bias")) return put(a->bqkv + E * 4, ESMK_DT_F32, E);
                 if (!strcmp(sub, "layer.v_proj.bias")) return put(a->bqkv + 2 * E * 4, ESMK_DT_F32, E);
-                if (!strcmp(sub, "layer.out_proj.weight")) return putw(a->wo, E, E, E, 0, 0, wsa);
+                if (!strcmp(sub, "layer.out_proj.weight")) return putw(a->wo, E, E, E, 0, 0, sp.o);
                 if (!strcmp(sub, "layer.out_proj.bias")) return put(a->bo, ESMK_DT_F32, E);
                 if (!strcmp(sub, "layer_norm.weight")) return put(a->lng, ESMK_DT_F32, E);
                 if (!strcmp(sub, "layer_norm.bias")) return put(a->lnb, ESMK_DT_F32, E);
                 return 0;
             }
-            if (!strcmp(sub, "feed_forward_layer.layer.fc1.weight")) return putw(o.w1, F, E, E, 0, 0, wsm);
+            if (!strcmp(sub, "feed_forward_layer.layer.fc1.weight")) return putw(o.w1, F, E, E, 0, 0, sp.ffn);
             if (!strcmp(sub, "feed_forward_layer.layer.fc1.bias")) return put(o.b1, ESMK_DT_F32, F);
-            if (!strcmp(sub, "feed_forward_layer.layer.fc2.weight")) return putw(o.w2, E, F, F, 0, 0, wsm);
+            if (!strcmp(sub, "feed_forward_layer.layer.fc2.weight")) return putw(o.w2, E, F, F, 0, 0, sp.ffn);
             if (!strcmp(sub, "feed_forward_layer.layer.fc2.bias")) return put(o.b2, ESMK_DT_F32, E);
             if (!strcmp(sub, "feed_forward_layer.layer_norm.weight")) return put(o.flng, ESMK_DT_F32, E);
             if (!strcmp(sub, "feed_forward_layer.layer_norm.bias")) return put(o.flnb, ESMK_DT_F32, E);
@@ -462,18 +462,18 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
             if (!strcmp(sub, "final_layer_norm.bias")) return ln_put(o.ln2b, FB_LN2B, FB_W1);
         }
         // q/k/v: output rows are head dims -> spread over 64 slots; input columns padded to Kp
-        if (!strcmp(sub, "self_attn.q_proj.weight")) return putw(o.wqkv, E, E, Kp, qkmap, 0, wsa);
-        if (!strcmp(sub, "self_attn.k_proj.weight")) return putw(o.wqkv + EA * Kp * os * wsa, E, E, Kp, qkmap, 0, wsa);
-        if (!strcmp(sub, "self_attn.v_proj.weight")) return putw(o.wqkv + 2 * EA * Kp * os * wsa, E, E, Kp, padmap, 0, wsa);
+        if (!strcmp(sub, "self_attn.q_proj.weight")) return putw(o.wqkv, E, E, Kp, qkmap, 0, sp.qk);
+        if (!strcmp(sub, "self_attn.k_proj.weight")) return putw(o.wqkv + EA * Kp * os * sp.qk, E, E, Kp, qkmap, 0, sp.qk);
+        if (!strcmp(sub, "self_attn.v_proj.weight")) return putw(o.wqkv + 2 * EA * Kp * os * sp.qk, E, E, Kp, padmap, 0, sp.v);
         if (!strcmp(sub, "self_attn.q_proj.bias")) return put2d(o.bqkv, ESMK_DT_F32, 1, E, EA, 0, qkmap);
         if (!strcmp(sub, "self_attn.k_proj.bias")) return put2d(o.bqkv + EA * 4, ESMK_DT_F32, 1, E, EA, 0, qkmap);
         if (!strcmp(sub, "self_attn.v_proj.bias")) return put2d(o.bqkv + 2 * EA * 4, ESMK_DT_F32, 1, E, EA, 0, padmap);
         // out_proj consumes the attention context: its input columns follow the same slot layout
-        if (!strcmp(sub, "self_attn.out_proj.weight")) return putw(o.wo, E, E, EA, 0, padmap, wsa);
+        if (!strcmp(sub, "self_attn.out_proj.weight")) return putw(o.wo, E, E, EA, 0, padmap, sp.o);
         if (!strcmp(sub, "self_attn.out_proj.bias")) return put(o.bo, ESMK_DT_F32, E);
-        if (!strcmp(sub, "fc1.weight")) return putw(o.w1, F, E, Kp, 0, 0, wsm);
+        if (!strcmp(sub, "fc1.weight")) return putw(o.w1, F, E, Kp, 0, 0, sp.ffn);
         if (!strcmp(sub, "fc1.bias")) return put(o.b1, ESMK_DT_F32, F);
-        if (!strcmp(sub, "fc2.weight")) return putw(o.w2, E, F, F, 0, 0, wsm);
+        if (!strcmp(sub, "fc2.weight")) return putw(o.w2, E, F, F, 0, 0, sp.ffn);
         if (!strcmp(sub, "fc2.bias")) return put(o.b2, ESMK_DT_F32, E);
         if (!strcmp(sub, "self_attn_layer_norm.weight")) return put(o.ln1g, ESMK_DT_F32, E);
         if (!strcmp(sub, "self_attn_layer_norm.bias")) return put(o.ln1b, ESMK_DT_F32, E);
@@ -682,10 +682,10 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
     };
     // a GEMM of the layer stack: with split weights (f16x2) the same kernel runs over the [N, 2K] hi | lo image, the
     // activations' K tile kt / 2 meeting W_hi (kt even) and W_lo (kt odd); FLOP / byte accounting stays algorithmic
-    const int wsf = split_attn(m) ? 2 : 1;       // q / k / v / out-projection weights
-    const int wsf_ffn = split_ffn(m) ? 2 : 1;    // fc1 / fc2 weights (f16x2a leaves them plain)
+    const int wsf = split_plan(m).qk;            // q / k weights: the v rows of the image start behind 2 EA rows of this length
+    const bool any_split = m->cfg.weight_split != 0;
     auto layer_gemm = [&](int cls, GemmArgs a, int epi, double out_bytes_per_elem) -> int {
-        if ((cls == PC_GEMM_FC1 || cls == PC_GEMM_FC2 ? wsf_ffn : wsf) == 1) return gemm(cls, a, epi, out_bytes_per_elem);
+        if (split_factor(m, cls, epi) == 1) return gemm(cls, a, epi, out_bytes_per_elem);
         const double fl = 2.0 * a.M * (double)a.N * a.K;
         const double by = ((double)a.M * a.K + 2.0 * a.N * a.K) * os + (double)a.M * a.N * out_bytes_per_elem;
         a.a_row_bytes = (long long)a.K * (long long)os;
@@ -840,7 +840,7 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
             ESMK_TRY(hipEventRecord(m->ev_join, m->side_stream));
             if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;  // q, k: weight rows [0,2EA)
             ESMK_TRY(hipStreamWaitEvent(st, m->ev_join, 0));
-        } else if (wsf == 1 && gemm_qkv_one_launch(g)) {
+        } else if (!any_split && gemm_qkv_one_launch(g)) {
             // small batches: q, k and v in one launch — same tiles, same bits, fewer rounds over the CUs (kernels.h, EPI_QKV_ALL)
             GemmArgs ga = g;
             ga.N = 3 * EA;

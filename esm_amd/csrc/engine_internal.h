@@ -103,10 +103,22 @@ struct esmk_model {
     int unit_cap = 0;
 };
 
-// Precision modes with split weights (esmk_config::weight_split): 1 = f16x2, every matrix of the layer stack as W_hi + W_lo;
-// 2 = f16x2a, the attention projections (q, k, v, out) only — a third of the GEMM work, most of the accuracy
-static inline bool split_attn(const esmk_model* m) { return m->cfg.weight_split == 1 || m->cfg.weight_split == 2; }
-static inline bool split_ffn(const esmk_model* m) { return m->cfg.weight_split == 1; }
+// Precision modes with split weights (esmk_config::weight_split): which matrices of a layer are kept as W_hi + W_lo (factor 2:
+// image rows of 2 K, two MFMA passes) — 1 = f16x2: all;  2 = f16x2a: the attention projections q, k, v, out (a third of the
+// GEMM work);  3 = f16x2v: the value path v, out only (a sixth of the GEMM work, most of f16x2a's accuracy: DESIGN.md I.2)
+struct SplitPlan {
+    int qk, v, o, ffn;
+};
+static inline SplitPlan split_plan(const esmk_model* m) {
+    switch (m->cfg.weight_split) {
+        case 1: return {2, 2, 2, 2};
+        case 2: return {2, 2, 2, 1};
+        case 3: return {1, 2, 2, 1};
+        default: return {1, 1, 1, 1};
+    }
+}
+// factor of one layer GEMM by its profiler class and epilogue (the v projection is the EPI_V_T launch of class PC_GEMM_QKV)
+static inline int split_factor(const esmk_model* m, int cls, int epi);
 
 // ---- per-kernel-class timing (esmk_profile_begin / _end): classes of both engines ---------------------------
 enum {
@@ -121,6 +133,13 @@ static const char* const kProfNames[PC_COUNT] = {
     // LayerNorm fold: the row-statistics entry pass and the per-LayerNorm finalize launches (tiny; the LayerNorm passes
     // themselves are GEMM epilogue work) — "layernorm" keeps the standalone LayerNorm kernel (with the fold: the final one)
     "ln_fold_stats"};
+
+static inline int split_factor(const esmk_model* m, int cls, int epi) {
+    const SplitPlan s = split_plan(m);
+    if (cls == PC_GEMM_QKV) return epi == esmk::EPI_V_T ? s.v : s.qk;
+    if (cls == PC_GEMM_OUT) return s.o;
+    return s.ffn;
+}
 
 // Brackets one launch with two events on the launch stream when profiling is enabled.
 struct ProfScope {

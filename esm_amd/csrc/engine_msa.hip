@@ -18,7 +18,7 @@ void plan_packed_msa(esmk_model* m) {
     const size_t E = m->E, F = m->F, V = m->V;
     // f16x2: every layer matrix as [rows, 2 cols] (hi | lo K tiles); f16x2a: the attention projections only
     const size_t ws = m->cfg.weight_split ? 2 : 1;
-    const size_t wsa = split_attn(m) ? 2 : 1, wsm = split_ffn(m) ? 2 : 1;
+    const SplitPlan sp = split_plan(m);
     Carve c;
     m->embed_f32 = c.take(V * E * 4);
     m->embed_op = c.take(V * E * os);
@@ -38,9 +38,9 @@ void plan_packed_msa(esmk_model* m) {
     m->ct_b = c.take(4);
     m->mlayer.resize(m->L);
     auto attn = [&](AttnOff& a) {
-        a.wqkv = c.take(3 * E * E * os * wsa);
+        a.wqkv = c.take(E * E * os * (2 * sp.qk + sp.v));
         a.bqkv = c.take(3 * E * 4);
-        a.wo = c.take(E * E * os * wsa);
+        a.wo = c.take(E * E * os * sp.o);
         a.bo = c.take(E * 4);
         a.lng = c.take(E * 4);
         a.lnb = c.take(E * 4);
@@ -49,9 +49,9 @@ void plan_packed_msa(esmk_model* m) {
         MsaLayerOff& o = m->mlayer[l];
         attn(o.row);
         attn(o.col);
-        o.w1 = c.take(F * E * os * wsm);
+        o.w1 = c.take(F * E * os * sp.ffn);
         o.b1 = c.take(F * 4);
-        o.w2 = c.take(E * F * os * wsm);
+        o.w2 = c.take(E * F * os * sp.ffn);
         o.b2 = c.take(E * 4);
         o.flng = c.take(E * 4);
         o.flnb = c.take(E * 4);
@@ -132,9 +132,9 @@ int esmk_msa_create(const esmk_msa_config* cfg, esmk_model** out) {
         return fail("esmk_msa_create: embed_dim and ffn_dim must be multiples of 64");
     if (cfg->operand_dtype != ESMK_F16 && cfg->operand_dtype != ESMK_BF16)
         return fail("esmk_msa_create: operand_dtype must be ESMK_F16 or ESMK_BF16");
-    if (cfg->weight_split < 0 || cfg->weight_split > 2) return fail("esmk_msa_create: weight_split must be 0 (off), 1 (f16x2) or 2 (f16x2a)");
+    if (cfg->weight_split < 0 || cfg->weight_split > 3) return fail("esmk_msa_create: weight_split must be 0 (off), 1 (f16x2), 2 (f16x2a) or 3 (f16x2v)");
     if (cfg->weight_split != 0 && cfg->operand_dtype != ESMK_F16)
-        return fail("esmk_msa_create: weight_split (precision modes f16x2 / f16x2a) needs operand_dtype ESMK_F16");
+        return fail("esmk_msa_create: weight_split (precision modes f16x2 / f16x2a / f16x2v) needs operand_dtype ESMK_F16");
     esmk_model* m = new esmk_model();
     memset(&m->cfg, 0, sizeof(m->cfg));
     m->cfg.num_layers = cfg->num_layers;
@@ -243,10 +243,9 @@ int esmk_msa_forward(esmk_model* m, const void* packed_dev, const int64_t* token
     };
     // a GEMM against a weight matrix of the layer stack: with split weights (f16x2) the same kernel runs over
     // the [N, 2K] hi | lo image, the activations' K tile kt / 2 meeting W_hi (kt even) and W_lo (kt odd)
-    const int wsf = split_attn(m) ? 2 : 1;       // q / k / v / out-projection weights of the two attention blocks
-    const int wsf_ffn = split_ffn(m) ? 2 : 1;    // fc1 / fc2 (f16x2a leaves them plain)
+    const int wsf = split_plan(m).qk;            // q / k weights: the v rows of the image start behind 2 E rows of this length
     auto wgemm = [&](int cls, GemmArgs a, int epi, double out_bytes_per_elem) -> int {
-        if ((cls == PC_GEMM_FC1 || cls == PC_GEMM_FC2 ? wsf_ffn : wsf) == 1) return gemm(cls, a, epi, out_bytes_per_elem);
+        if (split_factor(m, cls, epi) == 1) return gemm(cls, a, epi, out_bytes_per_elem);
         const double fl = 2.0 * a.M * (double)a.N * a.K;
         const double by = ((double)a.M * a.K + 2.0 * a.N * a.K) * os + (double)a.M * a.N * out_bytes_per_elem;
         a.a_row_bytes = (long long)a.K * (long long)os;

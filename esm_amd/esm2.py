@@ -97,9 +97,11 @@ def _weight_split():
     time.  ESM-2, ESM-1b and (since round 4) the MSA Transformer engine.
     ``ESM_AMD_OPERAND=f16x2a`` (round 6): the same for the ATTENTION projections only (q, k, v, out: a third of the GEMM
     work) — representations and logits inside 1e-3 in both norms at ~1.3x the plain step instead of 1.6x.
-    Returns esmk_config.weight_split: 0 off, 1 f16x2, 2 f16x2a."""
+    ``ESM_AMD_OPERAND=f16x2v``: the VALUE path only (v, out: a sixth of the GEMM work, ~1.2x) — most of f16x2a's gain on
+    representations and logits; q / k rounding matters for the attention maps / contact logits only.
+    Returns esmk_config.weight_split: 0 off, 1 f16x2, 2 f16x2a, 3 f16x2v."""
     env = os.environ.get("ESM_AMD_OPERAND", "").lower()
-    return 1 if env in ("f16x2", "fp16x2") else 2 if env in ("f16x2a", "fp16x2a") else 0
+    return {"f16x2": 1, "fp16x2": 1, "f16x2a": 2, "fp16x2a": 2, "f16x2v": 3, "fp16x2v": 3}.get(env, 0)
 
 
 def _ln_fold():
@@ -113,7 +115,7 @@ def _operand_dtype_for(param_dtype):
     env = os.environ.get("ESM_AMD_OPERAND", "").lower()
     if env in ("bf16", "bfloat16"):
         return torch.bfloat16
-    if env in ("f16", "fp16", "float16", "half", "f16x2", "fp16x2", "f16x2a", "fp16x2a"):
+    if env in ("f16", "fp16", "float16", "half", "f16x2", "fp16x2", "f16x2a", "fp16x2a", "f16x2v", "fp16x2v"):
         return torch.float16
     # fp16 operands keep the 33-layer stack within 1e-3 of the fp32 reference (bf16: ~5e-3)
     return torch.bfloat16 if param_dtype == torch.bfloat16 else torch.float16
@@ -173,7 +175,7 @@ class _Engine:
         self.N = N
         self.device = device
         self.operand_dtype = operand_dtype
-        self.weight_split = int(weight_split)  # esmk_config.weight_split: 0 off, 1 f16x2, 2 f16x2a
+        self.weight_split = int(weight_split)  # esmk_config.weight_split: 0 off, 1 f16x2, 2 f16x2a, 3 f16x2v
         self.ln_fold = _ln_fold()  # ESM_AMD_LN_FOLD at creation: a changed setting makes a new engine
         # ESM-1b / ESM-1v (esm_amd.esm1.ProteinBertModel) set these; ESM-2 leaves them at zero
         self.no_rope = int(getattr(model, "_engine_no_rope", 0))

@@ -73,7 +73,8 @@ typedef struct esmk_config {
      * disappears at 2x the GEMM time.  Parameter image 2x larger.  0 = plain fp16 / bf16 operands.
      * 2 = "f16x2a" (round 6): the same for the ATTENTION projections only (q, k, v, out_proj:
      * esm/multihead_attention.py:256-261,395 — a third of the GEMM work); fc1 / fc2 stay plain fp16, the LM head runs in
-     * fp32 as with 1.  Representations and logits inside 1e-3 in both norms at ~1.3x the plain step. */
+     * fp32 as with 1.  Representations and logits inside 1e-3 in both norms at ~1.3x the plain step.
+     * 3 = "f16x2v": the value path only (v_proj, out_proj: a sixth of the GEMM work, ~1.2x). */
     int32_t weight_split;
     /* LayerNorm fold (reference esm/modules.py:120-140, the two LayerNorm -> Linear pairs of a TransformerLayer): 1 = the
      * q/k/v and fc1 weights are packed multiplied by the LayerNorm weight and row-centred, the residual GEMMs emit the
@@ -160,7 +161,8 @@ typedef struct esmk_msa_config {
     int32_t operand_dtype;               /* ESMK_F16 or ESMK_BF16 */
     int32_t weight_split;                /* 1: precision mode f16x2 (see esmk_config::weight_split; operand_dtype ESMK_F16): every weight
                                             matrix of the axial layers as W_hi + W_lo, the LM head on the fp32 MFMA path;
-                                            2: f16x2a, the row / column attention projections only */
+                                            2: f16x2a, the row / column attention projections only; 3: f16x2v, their v / out
+                                            projections only */
 } esmk_msa_config;
 
 /* Replaces MSATransformer.__init__; the handle is packed with esmk_pack_weight (MSATransformer

@@ -79,11 +79,13 @@ def test_650m_dims_split_weights_meet_the_contract(monkeypatch):
     assert s["repr_l2"] < 0.7 * out["f16"]["repr_l2"], out
 
 
-def test_650m_dims_attention_split_mode(monkeypatch):
+@pytest.mark.parametrize("mode,sites,b_l2,b_mx", [("f16x2a", ("W!qk", "W!v", "W!o"), 7.2e-4, 8.5e-4), ("f16x2v", ("W!v", "W!o"), 7.6e-4, 9.0e-4)])
+def test_650m_dims_attention_split_mode(monkeypatch, mode, sites, b_l2, b_mx):
     """ESM_AMD_OPERAND=f16x2a (esmk_config.weight_split = 2, round 6): split weights on the ATTENTION projections only (q, k,
-    v, out — a third of the GEMM work; the feed-forward matrices stay plain fp16, the LM head runs in fp32 as in f16x2).
-    Against the fp32 oracle and against the floor of exactly this form (weights exact at those four sites): the engine is on
-    its floor (the ONE contract, L2 slack 1.10), the representation is inside 1e-3 with ~30 % margin in both norms (plain
+    v, out — a third of the GEMM work; the feed-forward matrices stay plain fp16, the LM head runs in fp32 as in f16x2);
+    f16x2v (weight_split = 3): the value path only (v, out — a sixth of the GEMM work).
+    Against the fp32 oracle and against the floor of exactly this form (weights exact at those sites): the engine is on
+    its floor (the ONE contract, L2 slack 1.10), the representation is inside 1e-3 with 25 - 30 % margin in both norms (plain
     mode: 3 - 5 %), the logits inside 1e-3 in L2."""
     import _contract as C
     from oracle.esm2_oracle import ALL_OPERANDS
@@ -93,24 +95,24 @@ def test_650m_dims_attention_split_mode(monkeypatch):
     sd32 = {k: v.float() for k, v in sd.items()}
     toks = synth_tokens(2, 128, seed=100)
     ref = esm2_forward(sd32, toks, L, H, repr_layers=[L])
-    floor = esm2_forward(sd32, toks, L, H, repr_layers=[L], inject=(frozenset(ALL_OPERANDS + ("W!qk", "W!v", "W!o")), torch.float16),
+    floor = esm2_forward(sd32, toks, L, H, repr_layers=[L], inject=(frozenset(ALL_OPERANDS + sites), torch.float16),
                          inject_head=None)
     with skip_param_init():
         model = esm.ESM2(L, E, H).eval()
     model.load_state_dict(sd)
     model = model.cuda()
-    monkeypatch.setenv("ESM_AMD_OPERAND", "f16x2a")
+    monkeypatch.setenv("ESM_AMD_OPERAND", mode)
     with torch.no_grad():
         o = model(toks.cuda(), repr_layers=[L])
         pk = model.forward_varlen(toks.cuda(), repr_layers=[L], min_saving=None)
     monkeypatch.delenv("ESM_AMD_OPERAND")
     assert model.ln_fold_active() is False  # split weights run the plain LayerNorm path
-    l2, mx = C.check_tensors("650M-dims f16x2a repr", o["representations"][L].cpu(), ref["representations"][L], floor["representations"][L],
+    l2, mx = C.check_tensors(f"650M-dims {mode} repr", o["representations"][L].cpu(), ref["representations"][L], floor["representations"][L],
                              hard_l2=True)
-    assert l2 < 7.2e-4 and mx < 8.5e-4, (l2, mx)   # floor of the form on these inputs: 6.5e-4 / 7.3e-4 (plain mode: 8.7e-4 / 9.7e-4)
-    l2, mx = C.check_tensors("650M-dims f16x2a logits", o["logits"].cpu(), ref["logits"], floor["logits"], deep=True)
-    assert l2 < 1e-3, (l2, mx)                      # floor 8.3e-4 / 1.05e-3 (plain mode: 1.19e-3 / 1.28e-3)
-    C.check_raw_argmax("650M-dims f16x2a token argmax", C.raw_argmax_agreement(o["logits"], ref["logits"]),
+    assert l2 < b_l2 and mx < b_mx, (l2, mx)   # f16x2a measured 6.39e-4 / 6.98e-4 (floor of the form 6.40e-4 / 7.41e-4; plain mode 8.7e-4 / 9.7e-4)
+    l2, mx = C.check_tensors(f"650M-dims {mode} logits", o["logits"].cpu(), ref["logits"], floor["logits"], deep=True)
+    assert l2 < 1e-3, (l2, mx)                 # f16x2a measured 8.26e-4 / 9.60e-4 (plain mode: 1.19e-3 / 1.28e-3)
+    C.check_raw_argmax(f"650M-dims {mode} token argmax", C.raw_argmax_agreement(o["logits"], ref["logits"]),
                        C.raw_argmax_agreement(floor["logits"], ref["logits"]))
     # the token-packed forward runs the same kernels: same bits
     assert torch.equal(pk["representations"][L], o["representations"][L]) and torch.equal(pk["logits"], o["logits"])
