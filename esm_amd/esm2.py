@@ -111,6 +111,23 @@ def _ln_fold():
     return 0 if v == "" else (1 if v not in ("0", "off", "false") else -1)
 
 
+# Medium batches as TWO half-batches on two HIP streams (round 6).  At 8 ... 32 sequences of ~1000 tokens the persistent GEMMs
+# end in partly filled rounds of tiles over the 256 CUs (B = 8: fc2 has 320 half-height tiles = 1.25 rounds); workgroups
+# without a tile exit at once, so the kernels of a second, independent half-batch take the idle CUs: + 9 % at B = 8 and 16,
+# nothing at B <= 4 (the halves quantise worse than the whole) and at B = 64 (whole rounds already)
+# (profiles/r6_dual_stream_probe.log).  Sequences are independent and every kernel is batch-invariant bit for bit, so the
+# results are the bits of the one-stream forward.  ``ESM_AMD_DUAL_STREAM=0`` switches it off, ``=lo:hi`` moves the row window
+# (tokens per forward call).
+def _dual_stream_window():
+    v = os.environ.get("ESM_AMD_DUAL_STREAM", "")
+    if v in ("0", "off", "false"):
+        return None
+    if ":" in v:
+        lo, hi = v.split(":", 1)
+        return int(lo), int(hi)
+    return 6144, 36864   # B = 6 ... 36 sequences of 1024 tokens
+
+
 def _operand_dtype_for(param_dtype):
     env = os.environ.get("ESM_AMD_OPERAND", "").lower()
     if env in ("bf16", "bfloat16"):
@@ -203,6 +220,10 @@ class _Engine:
             self.packed = torch.zeros(nbytes.value, dtype=torch.uint8, device=device)
         self.fingerprint = None
         self.workspace = None
+        self.workspace2 = None   # second half-batch of the dual-stream forward
+        self.stream2 = None
+        self.max_T = 0           # longest row a finished forward call has seen (its RoPE table exists and is ordered before us)
+        self.profiling = False
         self._named = None
 
     def close(self):
@@ -360,12 +381,41 @@ class ESM2(nn.Module):
                 contacts = torch.empty((B, S, S), **f32)
                 if S > 0:  # empty sequences: the reference returns an empty [B,0,0] map
                     flags |= N.OUT_CONTACTS
-            ws = eng.workspace_for(B, T, flags)
             layers_arr = (ctypes.c_int32 * max(1, len(repr_set)))(*repr_set)
-            outs_arr = (ctypes.c_void_p * max(1, len(repr_set)))(*[r.data_ptr() for r in reps])
-            N.check(N.lib.esmk_forward(
-                eng.handle, N.ptr(eng.packed), N.ptr(tok), B, T, layers_arr, len(repr_set), outs_arr,
-                flags, N.ptr(logits), N.ptr(attn), N.ptr(contacts), N.ptr(ws), ws.numel(), N.cur_stream()))
+            win = _dual_stream_window()
+            if (win is not None and B >= 2 and win[0] <= B * T <= win[1] and T <= eng.max_T and not eng.profiling
+                    and not torch.cuda.is_current_stream_capturing()):
+                # two half-batches, the second on the engine's own stream (see _dual_stream_window): same bits
+                cur = torch.cuda.current_stream(dev)
+                if eng.stream2 is None:
+                    eng.stream2 = torch.cuda.Stream(dev)
+                h = (B + 1) // 2
+                need = ctypes.c_size_t()
+                N.check(N.lib.esmk_workspace_bytes(eng.handle, h, T, flags, ctypes.byref(need)))
+                ws = eng.workspace_for(h, T, flags)
+                if eng.workspace2 is None or eng.workspace2.numel() < need.value:
+                    eng.workspace2 = None
+                    eng.workspace2 = torch.empty(need.value, dtype=torch.uint8, device=dev)
+                ready = torch.cuda.Event()
+                ready.record(cur)                      # tokens, weights and the output allocations are ordered before the side stream
+                eng.stream2.wait_event(ready)
+                for lo, hi, wsp, st in ((0, h, ws, cur), (h, B, eng.workspace2, eng.stream2)):
+                    part = lambda t: None if t is None else t[lo:hi]
+                    outs_arr = (ctypes.c_void_p * max(1, len(repr_set)))(*[r[lo:hi].data_ptr() for r in reps])
+                    N.check(N.lib.esmk_forward(
+                        eng.handle, N.ptr(eng.packed), N.ptr(tok[lo:hi]), hi - lo, T, layers_arr, len(repr_set), outs_arr,
+                        flags, N.ptr(part(logits)), N.ptr(part(attn)), N.ptr(part(contacts)), N.ptr(wsp), wsp.numel(),
+                        ctypes.c_void_p(st.cuda_stream)))
+                done = torch.cuda.Event()
+                done.record(eng.stream2)
+                cur.wait_event(done)                   # the caller's stream sees both halves
+            else:
+                ws = eng.workspace_for(B, T, flags)
+                outs_arr = (ctypes.c_void_p * max(1, len(repr_set)))(*[r.data_ptr() for r in reps])
+                N.check(N.lib.esmk_forward(
+                    eng.handle, N.ptr(eng.packed), N.ptr(tok), B, T, layers_arr, len(repr_set), outs_arr,
+                    flags, N.ptr(logits), N.ptr(attn), N.ptr(contacts), N.ptr(ws), ws.numel(), N.cur_stream()))
+                eng.max_T = max(eng.max_T, T)
         out_dt = w.dtype
         cast = lambda t: t if t.dtype == out_dt else t.to(out_dt)
         if contacts_only:
@@ -447,6 +497,7 @@ class ESM2(nn.Module):
         if self._engine is None:
             raise RuntimeError("run one forward before profiling")
         N.check(N.lib.esmk_profile_begin(self._engine.handle))
+        self._engine.profiling = True  # per-class events live on ONE stream: no dual-stream forward while armed
 
     def profile_end(self):
         """Stop profiling; returns [{name, launches, ms, flops, bytes}] summed over the calls."""
@@ -455,6 +506,7 @@ class ESM2(nn.Module):
         buf = (N.EsmkProfileEntry * 32)()
         n = ctypes.c_int()
         N.check(N.lib.esmk_profile_end(self._engine.handle, buf, 32, ctypes.byref(n)))
+        self._engine.profiling = False
         return [dict(name=buf[i].name.decode(), launches=buf[i].launches, ms=buf[i].ms, flops=buf[i].flops,
                      bytes=buf[i].bytes) for i in range(n.value)]
 

@@ -1,0 +1,64 @@
+"""ESM2.forward splits medium batches into two half-batches on two HIP streams (esm_amd/esm2.py _dual_stream_window, round 6:
+the second half's persistent kernels take the CUs the first half's partly filled rounds of tiles leave idle).  Sequences are
+independent and the kernels batch-invariant, so every output must carry the bits of the one-stream forward — representations,
+logits, attention maps, contacts, padded batches, odd batch sizes — and the caller's stream must see both halves."""
+import pytest
+import torch
+
+import esm
+from esm_amd.synth import synth_esm2_state_dict, synth_tokens
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(L, E, H, seed):
+    m = esm.ESM2(L, E, H).eval()
+    m.load_state_dict(synth_esm2_state_dict(L, E, H, seed=seed))
+    return m.cuda()
+
+
+@pytest.mark.parametrize("B,n,dims", [(8, 1022, (2, 1280, 20)), (7, 300, (3, 320, 20)), (2, 40, (2, 128, 2))])
+def test_two_half_batches_give_the_bits_of_one_stream(monkeypatch, B, n, dims):
+    L, E, H = dims
+    model = _model(L, E, H, seed=21)
+    toks = synth_tokens(B, n, seed=5)
+    toks[1, n // 2] = 2          # a padded sequence in the first half ...
+    toks[1, n // 2 + 1:] = 1
+    toks[B - 1, 17] = 32         # ... a <mask> in the second
+    toks = toks.cuda()
+    monkeypatch.setenv("ESM_AMD_DUAL_STREAM", "0")
+    with torch.no_grad():
+        one = model(toks, repr_layers=[0, 1, L], return_contacts=True)
+        one_c = model.predict_contacts(toks)
+    monkeypatch.setenv("ESM_AMD_DUAL_STREAM", "1:100000000")  # every batch of >= 2 sequences
+    with torch.no_grad():
+        two = model(toks, repr_layers=[0, 1, L], return_contacts=True)
+        two_c = model.predict_contacts(toks)
+        # consumed right away on the caller's stream: it must wait for the side stream's half
+        s = two["representations"][L].sum().item()
+    assert model._engine.stream2 is not None, "the dual-stream path did not run"
+    assert s == one["representations"][L].sum().item()
+    for l in (0, 1, L):
+        assert torch.equal(one["representations"][l], two["representations"][l]), l
+    for k in ("logits", "attentions", "contacts"):
+        assert torch.equal(one[k], two[k]), k
+    assert torch.equal(one_c, two_c)
+
+
+def test_default_window_and_switch(monkeypatch):
+    from esm_amd.esm2 import _dual_stream_window
+
+    monkeypatch.delenv("ESM_AMD_DUAL_STREAM", raising=False)
+    lo, hi = _dual_stream_window()
+    assert lo <= 8 * 1024 and 32 * 1024 <= hi and 64 * 1024 > hi and 4 * 1024 < lo  # B = 8 ... 32 in, the headline batch and B = 4 out
+    monkeypatch.setenv("ESM_AMD_DUAL_STREAM", "0")
+    assert _dual_stream_window() is None
+    # the first forward of a new length always runs on one stream (its RoPE table must exist before a side stream reads it)
+    monkeypatch.setenv("ESM_AMD_DUAL_STREAM", "1:100000000")
+    model = _model(2, 128, 2, seed=3)
+    toks = synth_tokens(4, 50, seed=2).cuda()
+    with torch.no_grad():
+        a = model(toks)
+        assert model._engine.stream2 is None
+        b = model(toks)
+    assert model._engine.stream2 is not None and torch.equal(a["logits"], b["logits"])

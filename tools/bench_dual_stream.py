@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--streams", type=int, default=2)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--seq-len", type=int, default=1022)
+    ap.add_argument("--one-thread", action="store_true", help="ONE host thread issues the sub-batches one after the other on their "
+                    "streams (what a forward() that splits its batch internally would do) instead of one thread per stream")
     a = ap.parse_args()
     L, E, H = ESM2_DIMS["esm2_t33_650M_UR50D"]
     sd = synth_esm2_state_dict(L, E, H, seed=0)
@@ -46,6 +48,26 @@ def main():
             t_single = (time.perf_counter() - t0) / a.steps
         ns = min(a.streams, B)
         parts = [toks[i * B // ns:(i + 1) * B // ns].contiguous() for i in range(ns)]
+        if a.one_thread:
+            outs = [None] * ns
+            with torch.no_grad():
+                def step():
+                    for i in range(ns):
+                        with torch.cuda.stream(streams[i]):
+                            outs[i] = models[i](parts[i], repr_layers=[L])
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    step()
+                torch.cuda.synchronize()
+                t_multi = (time.perf_counter() - t0) / a.steps
+            same = all(torch.equal(outs[i]["representations"][L], ref["representations"][L][i * B // ns:(i + 1) * B // ns]) for i in range(ns))
+            rs = B * a.seq_len
+            print(f"B = {B}: single stream {t_single * 1e3:7.3f} ms = {rs / t_single / 1e3:7.1f} k residues/s;  ONE thread, {ns} streams x B = {B // ns}: "
+                  f"{t_multi * 1e3:7.3f} ms = {rs / t_multi / 1e3:7.1f} k residues/s ({t_single / t_multi:.3f} x);  bits equal: {same}", flush=True)
+            continue
         outs = [None] * ns
         barrier = threading.Barrier(ns + 1)
 
