@@ -111,21 +111,27 @@ def _ln_fold():
     return 0 if v == "" else (1 if v not in ("0", "off", "false") else -1)
 
 
-# Medium batches as TWO half-batches on two HIP streams (round 6).  At 8 ... 32 sequences of ~1000 tokens the persistent GEMMs
-# end in partly filled rounds of tiles over the 256 CUs (B = 8: fc2 has 320 half-height tiles = 1.25 rounds); workgroups
-# without a tile exit at once, so the kernels of a second, independent half-batch take the idle CUs: + 9 % at B = 8 and 16,
-# nothing at B <= 4 (the halves quantise worse than the whole) and at B = 64 (whole rounds already)
-# (profiles/r6_dual_stream_probe.log).  Sequences are independent and every kernel is batch-invariant bit for bit, so the
-# results are the bits of the one-stream forward.  ``ESM_AMD_DUAL_STREAM=0`` switches it off, ``=lo:hi`` moves the row window
-# (tokens per forward call).
+# Small and medium batches as TWO half-batches on two HIP streams (round 6).  Below ~56 k rows the persistent GEMMs end in
+# partly filled rounds of tiles over the 256 CUs (B = 8 x 1024 tokens: fc2 has 320 half-height tiles = 1.25 rounds);
+# workgroups without a tile exit at once, so the kernels of a second, independent half-batch take the idle CUs.  Measured on
+# one box (650M dims, profiles/r6_dual_stream_probe.log), rows -> gain: 4096 + 3.9 %, 6144 - 1.2 %, 8192 + 9.4 %, 12288
+# + 2.4 %, 16384 + 7.9 %, 24576 + 2.4 %, 32768 + 2.1 %, 40960 + 6.9 %, 49152 + 2.2 %, 65536 + 0.6 % (whole rounds already);
+# the same per row count for other (B, T) shapes.  Sequences are independent and every kernel of the forward is batch-invariant
+# bit for bit, so the results are the bits of the one-stream forward (the fused contact map of predict_contacts, whose head
+# grouping depends on the batch size, stays on one stream).  ``ESM_AMD_DUAL_STREAM=0`` switches it off,
+# ``=lo:hi[,lo:hi...]`` sets the row windows (tokens per forward call).
 def _dual_stream_window():
     v = os.environ.get("ESM_AMD_DUAL_STREAM", "")
     if v in ("0", "off", "false"):
         return None
     if ":" in v:
-        lo, hi = v.split(":", 1)
-        return int(lo), int(hi)
-    return 6144, 36864   # B = 6 ... 36 sequences of 1024 tokens
+        return [tuple(int(x) for x in w.split(":", 1)) for w in v.split(",")]
+    return [(3584, 5120), (7168, 57344)]
+
+
+def _dual_stream_wanted(rows):
+    win = _dual_stream_window()
+    return win is not None and any(lo <= rows <= hi for lo, hi in win)
 
 
 def _operand_dtype_for(param_dtype):
@@ -224,6 +230,7 @@ class _Engine:
         self.stream2 = None
         self.max_T = 0           # longest row a finished forward call has seen (its RoPE table exists and is ordered before us)
         self.profiling = False
+        self.dual_calls = 0
         self._named = None
 
     def close(self):
@@ -382,8 +389,7 @@ class ESM2(nn.Module):
                 if S > 0:  # empty sequences: the reference returns an empty [B,0,0] map
                     flags |= N.OUT_CONTACTS
             layers_arr = (ctypes.c_int32 * max(1, len(repr_set)))(*repr_set)
-            win = _dual_stream_window()
-            if (win is not None and B >= 2 and win[0] <= B * T <= win[1] and T <= eng.max_T and not eng.profiling
+            if (B >= 2 and not contacts_only and _dual_stream_wanted(B * T) and T <= eng.max_T and not eng.profiling
                     and not torch.cuda.is_current_stream_capturing()):
                 # two half-batches, the second on the engine's own stream (see _dual_stream_window): same bits
                 cur = torch.cuda.current_stream(dev)
@@ -409,6 +415,7 @@ class ESM2(nn.Module):
                 done = torch.cuda.Event()
                 done.record(eng.stream2)
                 cur.wait_event(done)                   # the caller's stream sees both halves
+                eng.dual_calls += 1
             else:
                 ws = eng.workspace_for(B, T, flags)
                 outs_arr = (ctypes.c_void_p * max(1, len(repr_set)))(*[r.data_ptr() for r in reps])

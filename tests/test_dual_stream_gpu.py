@@ -30,13 +30,14 @@ def test_two_half_batches_give_the_bits_of_one_stream(monkeypatch, B, n, dims):
     with torch.no_grad():
         one = model(toks, repr_layers=[0, 1, L], return_contacts=True)
         one_c = model.predict_contacts(toks)
+    n_before = getattr(model._engine, "dual_calls", 0)
     monkeypatch.setenv("ESM_AMD_DUAL_STREAM", "1:100000000")  # every batch of >= 2 sequences
     with torch.no_grad():
         two = model(toks, repr_layers=[0, 1, L], return_contacts=True)
         two_c = model.predict_contacts(toks)
         # consumed right away on the caller's stream: it must wait for the side stream's half
         s = two["representations"][L].sum().item()
-    assert model._engine.stream2 is not None, "the dual-stream path did not run"
+    assert model._engine.stream2 is not None and model._engine.dual_calls == n_before + 1, "the dual-stream path did not run (once: the fused contact map stays on one stream)"
     assert s == one["representations"][L].sum().item()
     for l in (0, 1, L):
         assert torch.equal(one["representations"][l], two["representations"][l]), l
@@ -49,8 +50,10 @@ def test_default_window_and_switch(monkeypatch):
     from esm_amd.esm2 import _dual_stream_window
 
     monkeypatch.delenv("ESM_AMD_DUAL_STREAM", raising=False)
-    lo, hi = _dual_stream_window()
-    assert lo <= 8 * 1024 and 32 * 1024 <= hi and 64 * 1024 > hi and 4 * 1024 < lo  # B = 8 ... 32 in, the headline batch and B = 4 out
+    from esm_amd.esm2 import _dual_stream_wanted
+
+    assert all(_dual_stream_wanted(b * 1024) for b in (4, 8, 16, 32, 48))          # measured + 2 ... 9 %
+    assert not any(_dual_stream_wanted(b * 1024) for b in (1, 2, 6, 64, 128))      # measured <= 0 / whole rounds of tiles
     monkeypatch.setenv("ESM_AMD_DUAL_STREAM", "0")
     assert _dual_stream_window() is None
     # the first forward of a new length always runs on one stream (its RoPE table must exist before a side stream reads it)
