@@ -49,11 +49,11 @@ HBM_PEAK_GBS = 8000.0        # spec; 6.29 TB/s is the measured copy ceiling
 HBM_ACHIEVABLE_GBS = 6300.0
 DEFAULT_BATCH = {"esm2_650m": 64, "esm2_3b_contacts": 32, "msa1b": 1, "extract_650m": 64}
 PMC_DIR = os.path.join(ROOT, "profiles")
-PMC_ROUND = "r5"
+PMC_ROUND = "r6"
 
 
 def pmc_summary_path(workload, batch, ln_fold):
-    """profiles/r5_pmc_summary_<workload>[_b<B>][_plain].json: one file per (workload, per-GPU batch, LayerNorm-fold mode)
+    """profiles/r6_pmc_summary_<workload>[_b<B>][_plain].json: one file per (workload, per-GPU batch, LayerNorm-fold mode)
     — the default batch and the default (fold) mode carry no suffix.  tools/profile_bench.sh writes them."""
     tag = workload
     if batch not in (None, 0, DEFAULT_BATCH.get(workload)):
@@ -188,7 +188,7 @@ PMC_CLASS = {"gemm_qkv_rope": "gemm_qkv_rope(qk)"}
 
 def pmc_traffic(kernel_class, src_hash, workload="esm2_650m", batch=None, ln_fold=None):
     """HBM bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes (tools/profile_bench.sh ->
-    profiles/r5_pmc_summary_*.json; FETCH_SIZE doubled as the microarch guide prescribes for gfx950).  A figure is
+    profiles/r6_pmc_summary_*.json; FETCH_SIZE doubled as the microarch guide prescribes for gfx950).  A figure is
     reported ONLY when a summary exists for exactly this (workload, per-GPU batch, LayerNorm-fold mode) AND records the
     source hash of the library that is running — anything else is null with the reason (never a stale number, never
     another launch shape's number: VERDICT r4 Weak-6)."""

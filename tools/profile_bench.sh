@@ -15,6 +15,9 @@ B=${3:-$DB}
 FOLD=${4:-1}
 mkdir -p $OUT
 export TMPDIR=/tmp
+# per-launch figures describe the launches of the ONE-stream forward (bench.py's per-class HIP-event profile also runs one stream:
+# esm_amd/esm2.py profile_begin); the dual-stream split of small batches (ESM_AMD_DUAL_STREAM) only changes the timed `value`
+export ESM_AMD_DUAL_STREAM=0
 CMD="python bench.py --workload $WL --batch $B --steps 2 --warmup 1 --no-cpu-baseline --no-secondary"
 [ "$FOLD" = "0" ] && CMD="$CMD --ln-fold 0"
 [ "$WL" = "msa1b" ] && FOLDARG="" || FOLDARG="--ln-fold $FOLD"
