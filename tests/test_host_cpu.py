@@ -364,3 +364,26 @@ def test_pmc_summary_tells_the_two_residual_gemms_apart(tmp_path):
         assert k["gemm_out_proj"]["launches_profiled"] == 6 and k["gemm_fc2"]["launches_profiled"] == 6, tag
         assert k["gemm_out_proj"]["fetch_kib"] == want[0] and k["gemm_fc2"]["fetch_kib"] == want[1], tag
         assert k["gemm_fc1_gelu"]["fetch_kib"] == 7.0
+
+
+def test_environment_switches_of_the_python_engine(monkeypatch):
+    """ESM_AMD_OPERAND -> esmk_config.weight_split (0 off, 1 f16x2, 2 f16x2a, 3 f16x2v; round 6) and operand dtype;
+    ESM_AMD_DUAL_STREAM -> the row windows of the two-stream forward (default: the measured windows, the headline batch and
+    B = 6 outside; "0" off; "lo:hi[,lo:hi]" explicit)."""
+    from esm_amd import esm2
+
+    for env, want in (("", 0), ("f16", 0), ("bf16", 0), ("f16x2", 1), ("fp16x2", 1), ("f16x2a", 2), ("F16X2A", 2), ("f16x2v", 3)):
+        monkeypatch.setenv("ESM_AMD_OPERAND", env)
+        assert esm2._weight_split() == want, env
+        if want:
+            assert esm2._operand_dtype_for(torch.float32) == torch.float16
+    monkeypatch.delenv("ESM_AMD_OPERAND")
+    monkeypatch.delenv("ESM_AMD_DUAL_STREAM", raising=False)
+    on = [b for b in range(1, 130) if esm2._dual_stream_wanted(b * 1024)]
+    assert 4 in on and 8 in on and 16 in on and 32 in on and 48 in on
+    assert not {1, 2, 6, 64, 128} & set(on)
+    monkeypatch.setenv("ESM_AMD_DUAL_STREAM", "0")
+    assert esm2._dual_stream_window() is None and not esm2._dual_stream_wanted(8192)
+    monkeypatch.setenv("ESM_AMD_DUAL_STREAM", "100:200,1000:2000")
+    assert esm2._dual_stream_window() == [(100, 200), (1000, 2000)]
+    assert esm2._dual_stream_wanted(150) and esm2._dual_stream_wanted(2000) and not esm2._dual_stream_wanted(500)
