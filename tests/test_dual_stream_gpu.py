@@ -49,6 +49,14 @@ def test_two_half_batches_give_the_bits_of_one_stream(monkeypatch, B, n, dims):
         nb = int(nonpad[b].sum().item()) - 2                    # contact map of sequence b: its own residues
         assert torch.equal(one["contacts"][b, :nb, :nb], two["contacts"][b, :nb, :nb]), b
     assert torch.equal(one_c, two_c)
+    # nothing of a workspace may be read before it is written: both workspaces = 0xFF bytes (NaN in fp16 / fp32), padded batch again
+    model._engine.workspace.fill_(255)
+    model._engine.workspace2.fill_(255)
+    with torch.no_grad():
+        three = model(toks, repr_layers=[L])
+    assert model._engine.dual_calls == n_before + 2
+    assert torch.equal(one["representations"][L][nonpad], three["representations"][L][nonpad])
+    assert torch.equal(one["logits"][nonpad], three["logits"][nonpad])
 
 
 def test_default_window_and_switch(monkeypatch):
