@@ -130,8 +130,18 @@ def init_ranks(expect_world: int, backend: str):
     # every rank's share of the host's CPUs, decided on the affinity sets of all local ranks (one node: world == local_world)
     peers = None
     if hasattr(os, "sched_getaffinity") and world == local_world:
-        peers = [None] * world
-        dist.all_gather_object(peers, sorted(os.sched_getaffinity(0)))
+        try:  # a plain tensor all-gather of CPU bit masks (the collective path the probe above just exercised), never fatal
+            ncpu = 4096
+            mine = torch.zeros(ncpu, dtype=torch.uint8)
+            for c in os.sched_getaffinity(0):
+                if c < ncpu:
+                    mine[c] = 1
+            mine = mine.to(dev)
+            masks = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(masks, mine)
+            peers = [torch.nonzero(m.cpu()).flatten().tolist() for m in masks]
+        except Exception:
+            peers = None
     cpus = pin_rank_cpus(local_rank, local_world, peers=peers)
     if cpus:
         torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus))))
