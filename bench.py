@@ -159,7 +159,8 @@ def protocol_test(args):
 def operand_name():
     env = os.environ.get("ESM_AMD_OPERAND", "").lower()
     return ("bf16" if env in ("bf16", "bfloat16") else "f16x2" if env in ("f16x2", "fp16x2")
-            else "f16x2a" if env in ("f16x2a", "fp16x2a") else "f16x2v" if env in ("f16x2v", "fp16x2v") else "f16")
+            else "f16x2a" if env in ("f16x2a", "fp16x2a") else "f16x2v" if env in ("f16x2v", "fp16x2v")
+            else "f16x3" if env in ("f16x3", "fp16x3") else "f16")
 
 
 def library_build():
@@ -470,7 +471,9 @@ def operand_floor_report(sd, toks_cpu, L, H, r_ref, logits_ref=None, fold=False)
         kinds = [k for k in ALL_OPERANDS if not (operand_name() == "f16x2" and k == "W")] + (["FOLD"] if fold else [])
         if operand_name() in ("f16x2a", "f16x2v"):
             kinds += ["W!v", "W!o"] + (["W!qk"] if operand_name() == "f16x2a" else [])
-        head = {"inject_head": None} if operand_name() in ("f16x2", "f16x2a", "f16x2v") else {}
+        if operand_name() == "f16x3":  # weights and GEMM inputs both split: q / k, v and P are what is still rounded
+            kinds = ["QK", "V", "P"]
+        head = {"inject_head": None} if operand_name() in ("f16x2", "f16x2a", "f16x2v", "f16x3") else {}
         fl = esm2_forward(sd, toks_cpu, L, H, repr_layers=[L], inject=(frozenset(kinds), odt), **head)
         lg = fl["logits"].double()
         fl = fl["representations"][L].double()
@@ -505,6 +508,10 @@ SECONDARY = [  # --quick-baseline: the children's own CPU-oracle sample (parity 
     # headline line
     ("esm2_650m_f16x2a", ["--workload", "esm2_650m", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-secondary",
                           "--operand", "f16x2a", "--parity-ref", "{PARITY_REF}"], 90),
+    # precision mode f16x3 (round 6): weights AND GEMM inputs split — the mode in which EVERY output, contact logits included, is
+    # inside 1e-3 of the reference; config 3 with its T = 258 parity sample (representations, logits, contact logits)
+    ("esm2_3b_contacts_f16x3", ["--workload", "esm2_3b_contacts", "--steps", "2", "--warmup", "1", "--quick-baseline",
+                                "--operand", "f16x3"], 120),
     # data sensitivity: under the power cap the rates depend on the operand statistics — the headline
     # configuration once more on synthetic weights with sharper attention and wider LayerNorm gains (std 0.1).  qk_gain 2.5
     # (mean attention-row maximum 0.18 instead of 0.05) still is a non-chaotic network: value + its own parity sample;
@@ -870,7 +877,7 @@ def main():
     ap.add_argument("--ln-fold", type=int, choices=[0, 1], default=None,
                     help="LayerNorm fold of the engine (esmk_config.ln_fold, DESIGN.md 4.8): 1 = the per-layer LayerNorm passes "
                          "become GEMM epilogue work (the library default since round 5: faster at every batch size), 0 = off")
-    ap.add_argument("--operand", choices=["f16", "bf16", "f16x2", "f16x2a", "f16x2v"], default=None,
+    ap.add_argument("--operand", choices=["f16", "bf16", "f16x2", "f16x2a", "f16x2v", "f16x3"], default=None,
                     help="MFMA operand type (default f16; bf16 is ~4 %% faster at ~7e-3 relative error; f16x2 = fp16 with "
                          "split weights W = W_hi + W_lo: 2x GEMM time, ~40 %% lower error — the precision mode with "
                          "margin under the 1e-3 contract).  Sets ESM_AMD_OPERAND for this run.")

@@ -91,7 +91,10 @@ constexpr float LAZY_LIMIT = 4096.f;
 // half the LDS traffic (profiles/r5_attention_w64_and_resid_atomic_ab.log).  Removed.
 // HACK (timing experiments, results WRONG; ESMK_ATTN_HACK): 1 = no row-sum adds, 2 = no exponentials (p = score),
 // 4 = no P.V MFMAs, 8 = no QK^T MFMAs — which of VALU issue and the matrix pipe the kernel's time follows.
-template <typename T, int LAZY, bool BUF = true, int HACK = 0>
+// X3 (precision mode f16x3, esmk_config::weight_split 4): the context rows leave as the A operand of that mode's out-projection —
+// per head (= one 64-column K tile) hi | hi | lo, lo = T(v - T(v)), row stride 3 H 64 (elementwise.hip split3_rows_kernel is the
+// same layout from fp32 rows).  An instantiation of its own: the shipped kernel keeps its code.
+template <typename T, int LAZY, bool BUF = true, int HACK = 0, bool X3 = false>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
     const float* __restrict__ key_bias, const int* __restrict__ seq_info, T* __restrict__ ctx,
@@ -416,22 +419,35 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
     // per lane and cover whole 128-byte rows instead of 8-byte pieces of 32 different rows.
     using V4 = typename Op<T>::v4;
     char* wl = smem + wave * 4096;
+    constexpr int NPASS = X3 ? 2 : 1;                 // X3: the hi values, then their remainders, through the same slice
+    const size_t ldc = (size_t)H * (X3 ? 192 : 64);   // context row stride in elements
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int pass = 0; pass < NPASS; ++pass) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            V4 pk;
+        for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pk[e] = Op<T>::from(o[d][4 * g + e] * inv);
-            *reinterpret_cast<V4*>(wl + lm * 128 + (((4 * d + g) ^ (lm & 7)) << 4) + 8 * h) = pk;
+            for (int g = 0; g < 4; ++g) {
+                V4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = o[d][4 * g + e] * inv;
+                    const T hi = Op<T>::from(v);
+                    pk[e] = pass == 0 ? hi : Op<T>::from(v - Op<T>::to(hi));
+                }
+                *reinterpret_cast<V4*>(wl + lm * 128 + (((4 * d + g) ^ (lm & 7)) << 4) + 8 * h) = pk;
+            }
+        T* dst = ctx + ((size_t)b * Tlen + row0) * ldc + head * (X3 ? 192 : 64) + (pass == 1 ? 128 : 0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int pc = it * 64 + lane;
+            const int r = pc >> 3, c = pc & 7;
+            const V8 v = *reinterpret_cast<const V8*>(wl + r * 128 + ((c ^ (r & 7)) << 4));
+            if (q0 + r < Tseg) {
+                *reinterpret_cast<V8*>(dst + (size_t)(q0 + r) * ldc + c * 8) = v;
+                if constexpr (X3)
+                    if (pass == 0) *reinterpret_cast<V8*>(dst + (size_t)(q0 + r) * ldc + 64 + c * 8) = v;  // hi twice
+            }
         }
-    T* dst = ctx + ((size_t)b * Tlen + row0) * ((size_t)H * 64) + head * 64;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int pc = it * 64 + lane;
-        const int r = pc >> 3, c = pc & 7;
-        const V8 v = *reinterpret_cast<const V8*>(wl + r * 128 + ((c ^ (r & 7)) << 4));
-        if (q0 + r < Tseg) *reinterpret_cast<V8*>(dst + (size_t)(q0 + r) * ((size_t)H * 64) + c * 8) = v;
     }
     // log-sum-exp of the row in the log2 domain (the map kernels compute exp2(s - lse2))
     const int qrow = q0 + lm;
@@ -476,7 +492,7 @@ hipError_t launch_mma_keep_c_selftest(const void* a, const void* b, const float*
 static hipError_t launch_attention_impl(const void* q, const void* k, const void* vt, const float* key_bias,
                                         const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
                                         int operand_dtype, int fill_mode, const int* any_pad, hipStream_t st,
-                                        AttnSegs segs = AttnSegs(), int n_items = 0);
+                                        AttnSegs segs = AttnSegs(), int n_items = 0, bool x3 = false);
 
 // start-up stagger of the co-resident workgroups in shader cycles per wave slot (attn_fwd_kernel); < 0 = read
 // ESMK_ATTN_STAGGER on the first launch; esmk_debug_set("attn_stagger", cycles)
@@ -488,6 +504,12 @@ hipError_t launch_attention(const void* q, const void* k, const void* vt, const 
                             const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
                             int operand_dtype, hipStream_t st) {
     return launch_attention_impl(q, k, vt, key_bias, seq_info, ctx, lse, B, H, T, Tp, operand_dtype, 0, nullptr, st);
+}
+
+// precision mode f16x3: ctx [B*T, 3 H 64] in the hi | hi | lo layout of that mode's out-projection operand (attn_fwd_kernel X3)
+hipError_t launch_attention_x3(const void* q, const void* k, const void* vt, const float* key_bias, const int* seq_info, void* ctx3,
+                               float* lse, int B, int H, int T, int Tp, int operand_dtype, hipStream_t st) {
+    return launch_attention_impl(q, k, vt, key_bias, seq_info, ctx3, lse, B, H, T, Tp, operand_dtype, 0, nullptr, st, AttnSegs(), 0, true);
 }
 
 hipError_t launch_attention_fill(const void* q, const void* k, const void* vt, const float* key_fill,
@@ -508,8 +530,16 @@ hipError_t launch_attention_packed(const void* q, const void* k, const void* vt,
 static hipError_t launch_attention_impl(const void* q, const void* k, const void* vt, const float* key_bias,
                                         const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
                                         int operand_dtype, int fill_mode, const int* any_pad, hipStream_t st,
-                                        AttnSegs segs, int n_items) {
+                                        AttnSegs segs, int n_items, bool x3) {
     if (B <= 0 || H <= 0 || T <= 0 || Tp < T || (Tp & 63)) return hipErrorInvalidValue;
+    if (x3) {  // f16x3 precision mode: fp16 operands, padded batches (engine.hip)
+        if (operand_dtype != ESMK_DT_F16 || segs.work != nullptr || fill_mode != 0) return hipErrorInvalidValue;
+        const int nq3 = (T + 127) / 128;
+        hipLaunchKernelGGL((attn_fwd_kernel<_Float16, 1, true, 0, true>), dim3(nq3 * B * H), dim3(256), 0, st, (const _Float16*)q,
+                           (const _Float16*)k, (const _Float16*)vt, key_bias, seq_info, (_Float16*)ctx, lse, H, B * H, nq3, T, Tp, 1, 0,
+                           any_pad, segs, 0);
+        return hipGetLastError();
+    }
     const int nq = segs.work != nullptr ? n_items : (T + 127) / 128;
     dim3 grid(nq * B * H);
     // ESMK_ATTN (read once): bit 0 XCD-grouped grid (default on), bit 1 = textbook online softmax instead of the

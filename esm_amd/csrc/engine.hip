@@ -89,6 +89,7 @@ struct Workspace {
     size_t scale, key_bias, seq_info, keep, x, h, big, lse, ct_scratch, total;
     size_t h2 = 0, ln_part = 0, ln_mean = 0, ln_rstd = 0;  // LayerNorm fold
     int ln_parts = 0;
+    size_t a3 = 0, f32a = 0, ffn3 = 0;  // precision mode f16x3: hi | hi | lo operand rows, fp32 LayerNorm / fc1 outputs
     size_t ct_acc, ct_row, ct_col, ct_rowp, ct_colp, ct_wt;  // contacts without attention maps (contacts.hip)
     size_t q, k, vt;  // inside big
     int Tp;
@@ -129,6 +130,11 @@ Workspace plan_workspace(const esmk_model* m, int B, int T, uint32_t flags, int 
         w.ln_part = c.take(Np * w.ln_parts * 2 * 4);
         w.ln_mean = c.take(Np * 4);
         w.ln_rstd = c.take(Np * 4);
+    }
+    if (split_x3(m)) {
+        w.a3 = c.take(N * 3 * std::max(Kp, EA) * os);
+        w.f32a = c.take(N * std::max(E, F) * 4);
+        w.ffn3 = c.take(N * 3 * F * os);
     }
     const size_t qb = align_up(N * EA * os);
     const size_t vtb = align_up((size_t)B * EA * w.Tp * os);
@@ -249,9 +255,12 @@ int esmk_create(const esmk_config* cfg, esmk_model** out) {
                     "heads are spread over 64 slots at pack time)");
     if (cfg->embed_dim % 8 != 0 || cfg->ffn_dim % 64 != 0)
         return fail("esmk_create: embed_dim must be a multiple of 8 and ffn_dim a multiple of 64");
-    if (cfg->weight_split < 0 || cfg->weight_split > 3) return fail("esmk_create: weight_split must be 0 (off), 1 (f16x2), 2 (f16x2a) or 3 (f16x2v)");
+    if (cfg->weight_split < 0 || cfg->weight_split > 4)
+        return fail("esmk_create: weight_split must be 0 (off), 1 (f16x2), 2 (f16x2a), 3 (f16x2v) or 4 (f16x3)");
+    if (cfg->weight_split == 4 && (cfg->embed_dim % 64 != 0 || cfg->embed_dim / cfg->num_heads != 64))
+        return fail("esmk_create: weight_split 4 (f16x3) needs head_dim 64 and embed_dim % 64 == 0");
     if (cfg->weight_split != 0 && cfg->operand_dtype != ESMK_F16)
-        return fail("esmk_create: weight_split (precision modes f16x2 / f16x2a / f16x2v) needs operand_dtype ESMK_F16");
+        return fail("esmk_create: weight_split (precision modes f16x2 / f16x2a / f16x2v / f16x3) needs operand_dtype ESMK_F16");
     // LayerNorm fold: explicit request, or the library default / ESMK_LN_FOLD where the configuration supports it
     const bool fold_ok = cfg->weight_split == 0 && d <= 64;
     if (cfg->ln_fold > 0 && !fold_ok)
@@ -353,7 +362,7 @@ int esmk_pack_weight(esmk_model* m, void* packed_dev, size_t packed_bytes, const
         if (n != rows * cols)
             return fail(std::string("esmk_pack_weight: ") + key + " has " + std::to_string(n) +
                         " elements, expected " + std::to_string(rows * cols));
-        ESMK_TRY(launch_convert2d_split(src_dev, src_dtype, base + off, rows, cols, ld, rmap, cmap, hd, st));
+        ESMK_TRY(launch_convert2d_split(src_dev, src_dtype, base + off, rows, cols, ld, rmap, cmap, hd, st, (int)(split ? split : ws)));
         return 0;
     };
     if (!strcmp(key, "embed_tokens.weight")) {
@@ -684,6 +693,15 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
     // activations' K tile kt / 2 meeting W_hi (kt even) and W_lo (kt odd); FLOP / byte accounting stays algorithmic
     const int wsf = split_plan(m).qk;            // q / k weights: the v rows of the image start behind 2 EA rows of this length
     const bool any_split = m->cfg.weight_split != 0;
+    // Precision mode f16x3 (weight_split 4): every layer GEMM is a PLAIN launch over K' = 3 K — weight images hi | lo | hi per K
+    // tile, operand rows hi | hi | lo: a3 from the fp32 LayerNorm output (launch_split3_rows) and from the attention kernel's
+    // X3 output, ffn3 from fc1's fp32 GELU output
+    const bool x3 = split_x3(m);
+    if (x3 && (pc != nullptr || m->D != 64 || Kp != E || EA != E))
+        return fail("esmk_forward: the f16x3 precision mode runs padded batches of head_dim-64 models (no token-packed form)");
+    void* a3 = x3 ? (void*)(ws + w.a3) : nullptr;
+    float* f32a = x3 ? (float*)(ws + w.f32a) : nullptr;
+    void* ffn3 = x3 ? (void*)(ws + w.ffn3) : nullptr;
     auto layer_gemm = [&](int cls, GemmArgs a, int epi, double out_bytes_per_elem) -> int {
         if (split_factor(m, cls, epi) == 1) return gemm(cls, a, epi, out_bytes_per_elem);
         const double fl = 2.0 * a.M * (double)a.N * a.K;
@@ -700,6 +718,12 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         LnExtra ex;
         ex.ldy = Kp;  // normalised rows are K operands: row stride = E rounded up to the 64-wide K tile
         ESMK_TRY(launch_layernorm_ex(in, (const float*)(pk + go), (const float*)(pk + bo), y, y32, N, E, op, ex, st));
+        return 0;
+    };
+    auto ln_x3 = [&](size_t go, size_t bo) -> int {  // LayerNorm(x) in fp32 -> hi | hi | lo operand rows
+        if (lnorm(x, go, bo, nullptr, f32a)) return 1;
+        ProfScope ps(m, st, PC_LAYERNORM, 0, NE * (4 + 3 * os));
+        ESMK_TRY(launch_split3_rows(f32a, a3, (size_t)N, E, (size_t)E, (size_t)3 * E, st));
         return 0;
     };
     // LayerNorm fold: hA = raw rows of the residual stream in the operand dtype (written by rowstats for
@@ -794,7 +818,9 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         if (pc)  // only the spare key tile: every row below it is a computed (finite) row
             ESMK_TRY(hipMemset2DAsync((char*)vt + (size_t)T * os, (size_t)w.Tp * os, 0, 64 * os, (size_t)EA, st));
         else if (w.Tp != T) ESMK_TRY(hipMemsetAsync(vt, 0, (size_t)B * EA * w.Tp * os, st));
-        if (!fold) {
+        if (x3) {
+            if (ln_x3(o.ln1g, o.ln1b)) return 1;
+        } else if (!fold) {
             if (lnorm(x, o.ln1g, o.ln1b, h, nullptr)) return 1;
         } else if (l == 0) {  // entry of the fold chain: rows and statistics of the embedded stream
             ProfScope ps(m, st, PC_LN_STATS, 8 * NE, NE * (4 + os));
@@ -811,6 +837,10 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         g.M = N;
         g.N = 2 * EA;
         g.K = Kp;
+        if (x3) {
+            g.A = a3;
+            g.K = 3 * Kp;
+        }
         g.q = q;
         g.k = k;
         g.vt = vt;
@@ -845,6 +875,9 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
             GemmArgs ga = g;
             ga.N = 3 * EA;
             if (gemm(PC_GEMM_QKV, ga, EPI_QKV_ALL, os)) return 1;
+        } else if (x3) {
+            if (gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;
+            if (gemm(PC_GEMM_QKV, gv, EPI_V_T, os)) return 1;
         } else {
             if (layer_gemm(PC_GEMM_QKV, g, EPI_QKV_ROPE, os)) return 1;  // q, k: weight rows [0,2EA)
             if (layer_gemm(PC_GEMM_QKV, gv, EPI_V_T, os)) return 1;
@@ -858,6 +891,7 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
                 ESMK_TRY(launch_attention128_packed(q, k, vt, key_bias, hB, H, T, w.Tp, segs, pc->n_items, op, st));
             else if (pc) ESMK_TRY(launch_attention_packed(q, k, vt, key_bias, hB, H, T, w.Tp, segs, pc->n_items, op, st));
             else if (m->D == 128) ESMK_TRY(launch_attention128(q, k, vt, key_bias, seq_info, hB, lse, B, H, T, w.Tp, op, st));
+            else if (x3) ESMK_TRY(launch_attention_x3(q, k, vt, key_bias, seq_info, a3, lse, B, H, T, w.Tp, op, st));
             else ESMK_TRY(launch_attention(q, k, vt, key_bias, seq_info, hB, lse, B, H, T, w.Tp, op, st));
         }
         if (fused_ct && S_ct > 0) {
@@ -889,11 +923,18 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         g.N = E;
         g.K = EA;
         if (fold) producer(g);
+        if (x3) {
+            g.A = a3;
+            g.K = 3 * EA;
+            if (gemm(PC_GEMM_OUT, g, EPI_RESID_F32, 8)) return 1;
+            if (ln_x3(o.ln2g, o.ln2b)) return 1;
+        } else {
         if (layer_gemm(PC_GEMM_OUT, g, EPI_RESID_F32, fold ? 8 + os : 8)) return 1;
         if (fold) {
             if (finalize()) return 1;
         } else if (lnorm(x, o.ln2g, o.ln2b, h, nullptr)) {
             return 1;
+        }
         }
         g = GemmArgs();
         g.A = hA;
@@ -907,7 +948,16 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         g.M = N;
         g.N = F;
         g.K = Kp;
-        if (layer_gemm(PC_GEMM_FC1, g, EPI_GELU_T, os)) return 1;
+        if (x3) {  // fc1 + GELU in fp32, then the hi | hi | lo rows of fc2's operand
+            g.A = a3;
+            g.K = 3 * Kp;
+            g.out = f32a;
+            if (gemm(PC_GEMM_FC1, g, EPI_GELU_F32, 4)) return 1;
+            ProfScope ps(m, st, PC_GEMM_FC1, 0, (double)N * F * (4 + 3 * os));
+            ESMK_TRY(launch_split3_rows(f32a, ffn3, (size_t)N, F, (size_t)F, (size_t)3 * F, st));
+        } else if (layer_gemm(PC_GEMM_FC1, g, EPI_GELU_T, os)) {
+            return 1;
+        }
         g = GemmArgs();
         g.A = ffn;
         g.W = pk + o.w2;
@@ -918,6 +968,11 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         g.K = F;
         const bool feeds_next = fold && l + 1 < L;  // the next layer's q/k/v projections read the rows this GEMM writes
         if (feeds_next) producer(g);
+        if (x3) {
+            g.A = ffn3;
+            g.K = 3 * F;
+            if (gemm(PC_GEMM_FC2, g, EPI_RESID_F32, 8)) return 1;
+        } else
         if (layer_gemm(PC_GEMM_FC2, g, EPI_RESID_F32, feeds_next ? 8 + os : 8)) return 1;
         if (feeds_next && finalize()) return 1;
         if (l + 1 < L && repr_copy(l + 1, x)) return 1;  // esm2.py:117-118

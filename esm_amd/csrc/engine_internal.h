@@ -105,7 +105,9 @@ struct esmk_model {
 
 // Precision modes with split weights (esmk_config::weight_split): which matrices of a layer are kept as W_hi + W_lo (factor 2:
 // image rows of 2 K, two MFMA passes) — 1 = f16x2: all;  2 = f16x2a: the attention projections q, k, v, out (a third of the
-// GEMM work);  3 = f16x2v: the value path v, out only (a sixth of the GEMM work, most of f16x2a's accuracy: DESIGN.md I.2)
+// GEMM work);  3 = f16x2v: the value path v, out only (a sixth of the GEMM work, most of f16x2a's accuracy: DESIGN.md I.2);
+// 4 = f16x3: every matrix as hi | lo | hi (factor 3) against ACTIVATIONS laid out hi | hi | lo — weights and GEMM inputs both
+// to ~20 bits: the mode that holds 1e-3 on every output, contact logits included
 struct SplitPlan {
     int qk, v, o, ffn;
 };
@@ -114,9 +116,11 @@ static inline SplitPlan split_plan(const esmk_model* m) {
         case 1: return {2, 2, 2, 2};
         case 2: return {2, 2, 2, 1};
         case 3: return {1, 2, 2, 1};
+        case 4: return {3, 3, 3, 3};
         default: return {1, 1, 1, 1};
     }
 }
+static inline bool split_x3(const esmk_model* m) { return m->cfg.weight_split == 4; }
 // factor of one layer GEMM by its profiler class and epilogue (the v projection is the EPI_V_T launch of class PC_GEMM_QKV)
 static inline int split_factor(const esmk_model* m, int cls, int epi);
 

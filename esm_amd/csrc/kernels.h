@@ -159,8 +159,11 @@ hipError_t launch_convert2d(const void* src, int src_dtype, void* dst, int dst_d
 // split-weight image (operand mode f16x2): src [rows, cols] -> dst fp16 [rows, 2 dst_ld]; 64-column K tile t of row r
 // becomes hi = fp16(w) at dst[r][128 t .. +63] and lo = fp16(w - hi) at dst[r][128 t + 64 .. +127]
 // (hi + lo carries ~19-22 bits of w: the MFMA takes fp16 subnormals as they are); row_map / col_map as above
+// parts = 3 (operand mode f16x3): hi | lo | hi per K tile, rows of 3 dst_ld — against activation rows hi | hi | lo
+// (launch_split3_rows, attention's X3 output) a plain GEMM over K' = 3 K is A_hi W_hi + A_hi W_lo + A_lo W_hi
 hipError_t launch_convert2d_split(const void* src, int src_dtype, void* dst, size_t rows, size_t cols, size_t dst_ld,
-                                  int row_map, int col_map, int d, hipStream_t st);
+                                  int row_map, int col_map, int d, hipStream_t st, int parts = 2);
+hipError_t launch_split3_rows(const float* src, void* dst, size_t rows, int cols, size_t src_ld, size_t dst_ld, hipStream_t st);
 // RoPE tables cos/sin[t][i] = cos/sin(t * inv_freq[i]) (rotary_embedding.py:47-61), fp32
 hipError_t launch_rope_table(const float* inv_freq, float* cos, float* sin, int T, int half,
                              hipStream_t st);
@@ -220,6 +223,8 @@ hipError_t launch_attention128_packed(const void* q, const void* k, const void* 
 hipError_t launch_attention(const void* q, const void* k, const void* vt, const float* key_bias,
                             const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,
                             int operand_dtype, hipStream_t st);
+hipError_t launch_attention_x3(const void* q, const void* k, const void* vt, const float* key_bias, const int* seq_info, void* ctx3,
+                               float* lse, int B, int H, int T, int Tp, int operand_dtype, hipStream_t st);
 // attention128.hip: head_dim 128 (esm2_t48_15B)
 hipError_t launch_attention128(const void* q, const void* k, const void* vt, const float* key_bias,
                                const int* seq_info, void* ctx, float* lse, int B, int H, int T, int Tp,

@@ -99,9 +99,12 @@ def _weight_split():
     work) — representations and logits inside 1e-3 in both norms at ~1.3x the plain step instead of 1.6x.
     ``ESM_AMD_OPERAND=f16x2v``: the VALUE path only (v, out: a sixth of the GEMM work, ~1.2x) — most of f16x2a's gain on
     representations and logits; q / k rounding matters for the attention maps / contact logits only.
-    Returns esmk_config.weight_split: 0 off, 1 f16x2, 2 f16x2a, 3 f16x2v."""
+    ``ESM_AMD_OPERAND=f16x3``: weights AND GEMM inputs split (every layer GEMM a plain launch over K' = 3 K: A_hi W_hi +
+    A_hi W_lo + A_lo W_hi) — the mode that holds 1e-3 on EVERY output, contact logits included, at ~3x the step;
+    head_dim-64 models, padded batches (``forward_varlen`` falls back to ``forward``).
+    Returns esmk_config.weight_split: 0 off, 1 f16x2, 2 f16x2a, 3 f16x2v, 4 f16x3."""
     env = os.environ.get("ESM_AMD_OPERAND", "").lower()
-    return {"f16x2": 1, "fp16x2": 1, "f16x2a": 2, "fp16x2a": 2, "f16x2v": 3, "fp16x2v": 3}.get(env, 0)
+    return {"f16x2": 1, "fp16x2": 1, "f16x2a": 2, "fp16x2a": 2, "f16x2v": 3, "fp16x2v": 3, "f16x3": 4, "fp16x3": 4}.get(env, 0)
 
 
 def _ln_fold():
@@ -138,7 +141,7 @@ def _operand_dtype_for(param_dtype):
     env = os.environ.get("ESM_AMD_OPERAND", "").lower()
     if env in ("bf16", "bfloat16"):
         return torch.bfloat16
-    if env in ("f16", "fp16", "float16", "half", "f16x2", "fp16x2", "f16x2a", "fp16x2a", "f16x2v", "fp16x2v"):
+    if env in ("f16", "fp16", "float16", "half", "f16x2", "fp16x2", "f16x2a", "fp16x2a", "f16x2v", "fp16x2v", "f16x3", "fp16x3"):
         return torch.float16
     # fp16 operands keep the 33-layer stack within 1e-3 of the fp32 reference (bf16: ~5e-3)
     return torch.bfloat16 if param_dtype == torch.bfloat16 else torch.float16
@@ -467,8 +470,8 @@ class ESM2(nn.Module):
         B, T = tokens.shape
         L, E, V = self.num_layers, self.embed_dim, self.alphabet_size
         plan = pack_plan(tokens, self.padding_idx, lengths)
-        if unpack and min_saving is not None and plan.rows > (1.0 - min_saving) * B * T:
-            return self.forward(tokens.to(dev), repr_layers=repr_layers)
+        if unpack and ((min_saving is not None and plan.rows > (1.0 - min_saving) * B * T) or _weight_split() == 4):
+            return self.forward(tokens.to(dev), repr_layers=repr_layers)  # (f16x3 has no token-packed form)
         repr_set = sorted({int(i) for i in repr_layers if 0 <= int(i) <= L})
         with torch.cuda.device(dev):
             eng = self._get_engine(dev)

@@ -74,7 +74,11 @@ typedef struct esmk_config {
      * 2 = "f16x2a" (round 6): the same for the ATTENTION projections only (q, k, v, out_proj:
      * esm/multihead_attention.py:256-261,395 — a third of the GEMM work); fc1 / fc2 stay plain fp16, the LM head runs in
      * fp32 as with 1.  Representations and logits inside 1e-3 in both norms at ~1.3x the plain step.
-     * 3 = "f16x2v": the value path only (v_proj, out_proj: a sixth of the GEMM work, ~1.2x). */
+     * 3 = "f16x2v": the value path only (v_proj, out_proj: a sixth of the GEMM work, ~1.2x).
+     * 4 = "f16x3": weights AND GEMM inputs split — every matrix is packed hi | lo | hi per 64-column K tile and every layer
+     * GEMM runs as a plain launch over K' = 3 K on operand rows hi | hi | lo (A_hi W_hi + A_hi W_lo + A_lo W_hi); only q / k, v
+     * and P of the attention stay fp16.  Representations, logits AND contact logits inside 1e-3 of the reference
+     * (tests/test_readme.py:116 atol) at ~2.65x the step.  head_dim 64, embed_dim % 64 == 0, padded batches (esmk_forward). */
     int32_t weight_split;
     /* LayerNorm fold (reference esm/modules.py:120-140, the two LayerNorm -> Linear pairs of a TransformerLayer): 1 = the
      * q/k/v and fc1 weights are packed multiplied by the LayerNorm weight and row-centred, the residual GEMMs emit the

@@ -135,7 +135,7 @@ def test_secondary_workloads_glue(monkeypatch):
     import time as _t
 
     out = bench.secondary_workloads(extra=["--protocol-test"], budget_end=_t.perf_counter() + 1000)
-    assert list(out) == ["msa1b", "extract_650m", "esm2_3b_contacts", "esm2_650m_b4", "esm2_650m_f16x2a", "esm2_650m_sharp",
+    assert list(out) == ["msa1b", "extract_650m", "esm2_3b_contacts", "esm2_650m_b4", "esm2_650m_f16x2a", "esm2_3b_contacts_f16x3", "esm2_650m_sharp",
                          "esm2_650m_plain", "esm2_650m_b4_plain"]
     # the plain lines switch the LayerNorm fold off, the others leave the library default (on since round 5)
     assert out["esm2_650m_b4_plain"]["config"]["ln_fold"] == "0" and out["esm2_650m_plain"]["config"]["ln_fold"] == "0"
@@ -143,7 +143,7 @@ def test_secondary_workloads_glue(monkeypatch):
     for name, r in out.items():
         assert "error" not in r, (name, r)
         assert r["metric"].startswith("protocol-test") and r["ms_per_step"] >= 4.5 and r["wall_s"] > 0
-    assert out["esm2_3b_contacts"]["steps"] == 4 and out["extract_650m"]["steps"] == 24 and out["extract_650m"]["warmup"] == 2
+    assert out["esm2_3b_contacts"]["steps"] == 4 and out["esm2_3b_contacts_f16x3"]["steps"] == 2 and out["extract_650m"]["steps"] == 24 and out["extract_650m"]["warmup"] == 2
     # a child that fails or overruns its limit is an entry with "error", not an exception
     monkeypatch.setattr(bench, "SECONDARY", [("bad_flag", ["--no-such-flag"], 60), ("too_slow", ["--steps", "400"], 1)])
     monkeypatch.setattr(bench, "SECONDARY_MIN_S", 0.5)

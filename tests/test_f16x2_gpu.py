@@ -116,3 +116,46 @@ def test_650m_dims_attention_split_mode(monkeypatch, mode, sites, b_l2, b_mx):
                        C.raw_argmax_agreement(floor["logits"], ref["logits"]))
     # the token-packed forward runs the same kernels: same bits
     assert torch.equal(pk["representations"][L], o["representations"][L]) and torch.equal(pk["logits"], o["logits"])
+
+
+def test_650m_dims_f16x3_weights_and_activations_split(monkeypatch):
+    """ESM_AMD_OPERAND=f16x3 (esmk_config.weight_split = 4, round 6): every layer GEMM as a plain launch over K' = 3 K — weight
+    images hi | lo | hi per K tile against operand rows hi | hi | lo (LayerNorm output and fc1's GELU output in fp32 ->
+    split3_rows_kernel; the attention kernel's X3 output) = A_hi W_hi + A_hi W_lo + A_lo W_hi; fp32 LM head.  What is still
+    rounded to fp16: q / k, v and P inside the attention.  The engine sits on the floor of exactly that form and every output is
+    inside 1e-3 with >= 2 x margin on representations and logits (contact logits: the full-size 3B test)."""
+    import _contract as C
+
+    L, E, H = 33, 1280, 20
+    sd = synth_esm2_state_dict(L, E, H, seed=0)
+    sd32 = {k: v.float() for k, v in sd.items()}
+    toks = synth_tokens(2, 128, seed=100)
+    toks[1, 90] = 2
+    toks[1, 91:] = 1
+    nonpad = toks.ne(1)
+    ref = esm2_forward(sd32, toks, L, H, repr_layers=[L], return_contacts=True)
+    floor = esm2_forward(sd32, toks, L, H, repr_layers=[L], return_contacts=True, inject=(frozenset({"QK", "V", "P"}), torch.float16),
+                         inject_head=None)
+    with skip_param_init():
+        model = esm.ESM2(L, E, H).eval()
+    model.load_state_dict(sd)
+    model = model.cuda()
+    monkeypatch.setenv("ESM_AMD_OPERAND", "f16x3")
+    with torch.no_grad():
+        o = model(toks.cuda(), repr_layers=[L], return_contacts=True)
+        fused = model.predict_contacts(toks.cuda())
+        pk = model.forward_varlen(toks.cuda(), repr_layers=[L], min_saving=None)  # no packed form in this mode: the padded forward
+    monkeypatch.delenv("ESM_AMD_OPERAND")
+    l2, mx = C.check_tensors("650M-dims f16x3 repr", o["representations"][L].cpu(), ref["representations"][L], floor["representations"][L],
+                             nonpad, hard_l2=True)
+    assert l2 < 4.5e-4 and mx < 5.5e-4, (l2, mx)
+    l2, mx = C.check_tensors("650M-dims f16x3 logits", o["logits"].cpu(), ref["logits"], floor["logits"], nonpad, deep=True)
+    assert l2 < 6e-4 and mx < 8e-4, (l2, mx)
+    C.check_raw_argmax("650M-dims f16x3 token argmax", C.raw_argmax_agreement(o["logits"], ref["logits"], nonpad),
+                       C.raw_argmax_agreement(floor["logits"], ref["logits"], nonpad))
+    for b, n in ((0, 128), (1, 89)):
+        _, zrel = C.contact_logit_errors(o["contacts"][b, :n, :n], ref["contacts"][b, :n, :n])
+        _, zfl = C.contact_logit_errors(floor["contacts"][b, :n, :n], ref["contacts"][b, :n, :n])
+        C.check(f"650M-dims f16x3 contact logits seq {b}", zrel, zrel, zfl, zfl, slack=C.CONTACT_SLACK, slack_l2=C.CONTACT_SLACK)
+        assert (fused[b, :n, :n].cpu() - o["contacts"][b, :n, :n].cpu()).abs().max().item() < 1e-4
+    assert torch.equal(pk["representations"][L][nonpad.cuda()], o["representations"][L][nonpad.cuda()])

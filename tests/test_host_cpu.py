@@ -372,7 +372,7 @@ def test_environment_switches_of_the_python_engine(monkeypatch):
     B = 6 outside; "0" off; "lo:hi[,lo:hi]" explicit)."""
     from esm_amd import esm2
 
-    for env, want in (("", 0), ("f16", 0), ("bf16", 0), ("f16x2", 1), ("fp16x2", 1), ("f16x2a", 2), ("F16X2A", 2), ("f16x2v", 3)):
+    for env, want in (("", 0), ("f16", 0), ("bf16", 0), ("f16x2", 1), ("fp16x2", 1), ("f16x2a", 2), ("F16X2A", 2), ("f16x2v", 3), ("f16x3", 4)):
         monkeypatch.setenv("ESM_AMD_OPERAND", env)
         assert esm2._weight_split() == want, env
         if want:
