@@ -91,7 +91,7 @@ def test_attention_keeps_three_waves_per_simd(asm):
     isa, paths = asm
     meta = isa.meta(paths["attention.hip"])
     # the shipped instantiations: lazy offset, buffer-load staging, nothing removed (LAZY = 1, BUF = true, HACK = 0), f16 and bf16
-    kernels = [k for k in meta if "attn_fwd_kernel" in k and "Li1ELb1ELi0EE" in k]
+    kernels = [k for k in meta if "attn_fwd_kernel" in k and "Li1ELb1ELi0ELb0EE" in k]
     assert len(kernels) == 2, kernels
     for k in kernels:
         vgpr, accum, scratch = meta[k]
