@@ -92,8 +92,8 @@ constexpr float LAZY_LIMIT = 4096.f;
 // HACK (timing experiments, results WRONG; ESMK_ATTN_HACK): 1 = no row-sum adds, 2 = no exponentials (p = score),
 // 4 = no P.V MFMAs, 8 = no QK^T MFMAs — which of VALU issue and the matrix pipe the kernel's time follows.
 // X3 (precision mode f16x3, esmk_config::weight_split 4): the context rows leave as the A operand of that mode's out-projection —
-// per head (= one 64-column K tile) hi | hi | lo, lo = T(v - T(v)), row stride 3 H 64 (elementwise.hip split3_rows_kernel is the
-// same layout from fp32 rows).  An instantiation of its own: the shipped kernel keeps its code.
+// per head (= one 64-column K tile) hi | hi | lo, lo = T(v - T(v)), row stride 3 H 64 (the layout the LayerNorm kernel writes
+// with LnExtra::x3).  An instantiation of its own: the shipped kernel keeps its code.
 template <typename T, int LAZY, bool BUF = true, int HACK = 0, bool X3 = false>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,

@@ -357,7 +357,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                     const int rr = rem / ex.map_C, cc = rem - rr * ex.map_C;
                     row = (b * ex.map_C + cc) * ex.map_R + rr;
                 }
-                if (y) {
+                if (y && ex.x3) {  // f16x3: hi | hi | lo per 64-column K tile (kernels.h LnExtra::x3)
+                    typename Op<T>::v4 pk, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pk[e] = Op<T>::from(o[e]);
+                        lo[e] = Op<T>::from(o[e] - Op<T>::to(pk[e]));
+                    }
+                    const int col = c * 4;
+                    T* q = y + (size_t)row * ex.ldy + (size_t)(col >> 6) * 192 + (col & 63);
+                    *reinterpret_cast<typename Op<T>::v4*>(q) = pk;
+                    *reinterpret_cast<typename Op<T>::v4*>(q + 64) = pk;
+                    *reinterpret_cast<typename Op<T>::v4*>(q + 128) = lo;
+                } else if (y) {
                     typename Op<T>::v4 pk;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) pk[e] = Op<T>::from(o[e]);
@@ -674,7 +686,7 @@ static hipError_t convert2d_from(const S* src, void* dst, int dst_dtype, size_t 
 }
 
 // THIRD (precision mode f16x3, esmk_config::weight_split 4): every 64-column K tile as hi | lo | hi (rows of 3 dst_ld) — against
-// activation rows laid out hi | hi | lo (split3_rows_kernel below) a PLAIN GEMM over K' = 3 K computes
+// activation rows laid out hi | hi | lo (layernorm_kernel LnExtra::x3, gemm9's X3O GELU epilogue, attn_fwd_kernel X3) a PLAIN GEMM over K' = 3 K computes
 // A_hi W_hi + A_hi W_lo + A_lo W_hi, i.e. the product of the operands to ~20 bits each (A_lo W_lo, 2^-22, is dropped).
 template <typename S, bool THIRD = false>
 __global__ __launch_bounds__(256) void convert2d_split_kernel(const S* __restrict__ src, _Float16* __restrict__ dst,
@@ -695,38 +707,6 @@ __global__ __launch_bounds__(256) void convert2d_split_kernel(const S* __restric
         q[64] = lo;
         if constexpr (THIRD) q[128] = hi;
     }
-}
-
-// fp32 rows [rows, cols] (row stride src_ld) -> fp16 rows of 3 cols (row stride dst_ld >= 3 cols): K tile t = hi | hi | lo of
-// columns [64 t, 64 t + 64), lo = fp16(x - fp16(x)) — the A operand of the f16x3 mode's GEMMs.  cols % 64 == 0.  Eight
-// columns per thread: two 16-byte loads, three 16-byte stores.
-__global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t rows,
-                                                           int cols, size_t src_ld, size_t dst_ld) {
-    const size_t per_row = (size_t)cols >> 3, n = rows * per_row;
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const size_t r = i / per_row;
-        const int c = (int)(i - r * per_row) << 3;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(src + r * src_ld + c), b = *reinterpret_cast<const f32x4*>(src + r * src_ld + c + 4);
-        f16x8 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            hi[e] = (_Float16)a[e], hi[4 + e] = (_Float16)b[e];
-            lo[e] = (_Float16)(a[e] - (float)hi[e]), lo[4 + e] = (_Float16)(b[e] - (float)hi[4 + e]);
-        }
-        _Float16* q = dst + r * dst_ld + (size_t)(c >> 6) * 192 + (c & 63);
-        *reinterpret_cast<f16x8*>(q) = hi;
-        *reinterpret_cast<f16x8*>(q + 64) = hi;
-        *reinterpret_cast<f16x8*>(q + 128) = lo;
-    }
-}
-
-hipError_t launch_split3_rows(const float* src, void* dst, size_t rows, int cols, size_t src_ld, size_t dst_ld, hipStream_t st) {
-    if (rows == 0 || cols <= 0) return hipSuccess;
-    if (cols % 64 != 0 || src_ld % 4 != 0 || dst_ld % 8 != 0 || dst_ld < (size_t)3 * cols) return hipErrorInvalidValue;
-    const unsigned blocks = (unsigned)std::min<size_t>((rows * (size_t)(cols >> 3) + 255) / 256, 16384);
-    hipLaunchKernelGGL(split3_rows_kernel, dim3(blocks), dim3(256), 0, st, src, (_Float16*)dst, rows, cols, src_ld, dst_ld);
-    return hipGetLastError();
 }
 
 hipError_t launch_convert2d_split(const void* src, int src_dtype, void* dst, size_t rows, size_t cols, size_t dst_ld,

@@ -89,7 +89,7 @@ struct Workspace {
     size_t scale, key_bias, seq_info, keep, x, h, big, lse, ct_scratch, total;
     size_t h2 = 0, ln_part = 0, ln_mean = 0, ln_rstd = 0;  // LayerNorm fold
     int ln_parts = 0;
-    size_t a3 = 0, f32a = 0, ffn3 = 0;  // precision mode f16x3: hi | hi | lo operand rows, fp32 LayerNorm / fc1 outputs
+    size_t a3 = 0, ffn3 = 0;  // precision mode f16x3: hi | hi | lo operand rows (LayerNorm output / attention context; fc1 + GELU output)
     size_t ct_acc, ct_row, ct_col, ct_rowp, ct_colp, ct_wt;  // contacts without attention maps (contacts.hip)
     size_t q, k, vt;  // inside big
     int Tp;
@@ -133,7 +133,6 @@ Workspace plan_workspace(const esmk_model* m, int B, int T, uint32_t flags, int 
     }
     if (split_x3(m)) {
         w.a3 = c.take(N * 3 * std::max(Kp, EA) * os);
-        w.f32a = c.take(N * std::max(E, F) * 4);
         w.ffn3 = c.take(N * 3 * F * os);
     }
     const size_t qb = align_up(N * EA * os);
@@ -694,13 +693,12 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
     const int wsf = split_plan(m).qk;            // q / k weights: the v rows of the image start behind 2 EA rows of this length
     const bool any_split = m->cfg.weight_split != 0;
     // Precision mode f16x3 (weight_split 4): every layer GEMM is a PLAIN launch over K' = 3 K — weight images hi | lo | hi per K
-    // tile, operand rows hi | hi | lo: a3 from the fp32 LayerNorm output (launch_split3_rows) and from the attention kernel's
-    // X3 output, ffn3 from fc1's fp32 GELU output
+    // tile, operand rows hi | hi | lo: a3 from the LayerNorm kernel (LnExtra::x3) and from the attention kernel's X3 output,
+    // ffn3 from fc1's GELU epilogue (GemmArgs::x3_out)
     const bool x3 = split_x3(m);
     if (x3 && (pc != nullptr || m->D != 64 || Kp != E || EA != E))
         return fail("esmk_forward: the f16x3 precision mode runs padded batches of head_dim-64 models (no token-packed form)");
     void* a3 = x3 ? (void*)(ws + w.a3) : nullptr;
-    float* f32a = x3 ? (float*)(ws + w.f32a) : nullptr;
     void* ffn3 = x3 ? (void*)(ws + w.ffn3) : nullptr;
     auto layer_gemm = [&](int cls, GemmArgs a, int epi, double out_bytes_per_elem) -> int {
         if (split_factor(m, cls, epi) == 1) return gemm(cls, a, epi, out_bytes_per_elem);
@@ -720,10 +718,12 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         ESMK_TRY(launch_layernorm_ex(in, (const float*)(pk + go), (const float*)(pk + bo), y, y32, N, E, op, ex, st));
         return 0;
     };
-    auto ln_x3 = [&](size_t go, size_t bo) -> int {  // LayerNorm(x) in fp32 -> hi | hi | lo operand rows
-        if (lnorm(x, go, bo, nullptr, f32a)) return 1;
-        ProfScope ps(m, st, PC_LAYERNORM, 0, NE * (4 + 3 * os));
-        ESMK_TRY(launch_split3_rows(f32a, a3, (size_t)N, E, (size_t)E, (size_t)3 * E, st));
+    auto ln_x3 = [&](size_t go, size_t bo) -> int {  // LayerNorm(x) -> hi | hi | lo operand rows (LnExtra::x3)
+        ProfScope ps(m, st, PC_LAYERNORM, 8 * NE, NE * (4 + 3 * os));
+        LnExtra ex;
+        ex.ldy = 3 * E;
+        ex.x3 = 1;
+        ESMK_TRY(launch_layernorm_ex(x, (const float*)(pk + go), (const float*)(pk + bo), a3, nullptr, N, E, op, ex, st));
         return 0;
     };
     // LayerNorm fold: hA = raw rows of the residual stream in the operand dtype (written by rowstats for
@@ -948,13 +948,12 @@ static int forward_impl(esmk_model* m, const void* packed_dev, const int64_t* to
         g.M = N;
         g.N = F;
         g.K = Kp;
-        if (x3) {  // fc1 + GELU in fp32, then the hi | hi | lo rows of fc2's operand
+        if (x3) {  // fc1 + GELU writing the hi | hi | lo rows of fc2's operand (GemmArgs::x3_out)
             g.A = a3;
             g.K = 3 * Kp;
-            g.out = f32a;
-            if (gemm(PC_GEMM_FC1, g, EPI_GELU_F32, 4)) return 1;
-            ProfScope ps(m, st, PC_GEMM_FC1, 0, (double)N * F * (4 + 3 * os));
-            ESMK_TRY(launch_split3_rows(f32a, ffn3, (size_t)N, F, (size_t)F, (size_t)3 * F, st));
+            g.out = ffn3;
+            g.x3_out = 1;
+            if (gemm(PC_GEMM_FC1, g, EPI_GELU_T, 3 * os)) return 1;
         } else if (layer_gemm(PC_GEMM_FC1, g, EPI_GELU_T, os)) {
             return 1;
         }

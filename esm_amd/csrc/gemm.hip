@@ -463,6 +463,12 @@ hipError_t launch_gemm(const GemmArgs& p, int epi, int operand_dtype, hipStream_
         const char* e = getenv("ESMK_GEMM");
         return e != nullptr && strcmp(e, "old") == 0;
     }();
+    if (p.x3_out) {  // the hi | hi | lo output form of the f16x3 mode exists in gemm9 only (full-height tiles)
+        if (!gemm9_supports(p, epi)) return hipErrorInvalidValue;
+        GemmArgs q = p;
+        q.half_m = 0;
+        return launch_gemm9(q, epi, operand_dtype, 0, st);
+    }
     // the LayerNorm-fold forms of the epilogues exist in gemm9 only: such a call never takes another kernel
     const bool lnf = gemm9_ln_fold(p, epi);
     if (lnf && !gemm9_supports(p, epi)) return hipErrorInvalidValue;

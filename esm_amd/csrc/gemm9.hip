@@ -242,8 +242,10 @@ ESMK_DEV void epilogue9_f32(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base,
 // LNF: LayerNorm-fold consumer (kernels.h, GemmArgs::ln_rstd): the accumulators hold raw_row . W''^T (no bias); the value
 // is ln_rstd[m] * acc + (bias[n] + bias2[n]) — ONE fma per element; in the q / k epilogue it replaces the multiply by the
 // q scale (rstd * scale and (bias + bias2) * scale are formed once per row / per 64-column half).
-template <typename T, int EPI, bool FULL, bool NT = false, int NMI = 8, int RR = 32, bool LNF = false>
+// X3O (EPI_GELU_T, precision mode f16x3): the rows leave in the hi | hi | lo layout of that mode's operands (GemmArgs::x3_out).
+template <typename T, int EPI, bool FULL, bool NT = false, int NMI = 8, int RR = 32, bool LNF = false, bool X3O = false>
 ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base, int n_base, int lane, char* wl) {
+    static_assert(!X3O || (EPI == EPI_GELU_T && !LNF), "hi | hi | lo output rows: the plain GELU epilogue");
     using V8 = typename Op<T>::v8;
     float bs1[8], bs2[8];  // LNF: bias + bias2 of the lane's columns in the current 64-column half (q: times the scale)
     // LNF: rstd of every row this lane visits (row RR i + RPI it + lane / LPR of the block), all loads in flight at once —
@@ -405,11 +407,23 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base, i
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], rs, bs1[e]);
                 }
-                if constexpr (EPI == EPI_GELU_T) gelu_fast_x8<true>(v);  // four chains: one wave per SIMD has no partner to fill VALU gaps
+                if constexpr (EPI == EPI_GELU_T) gelu_fast_x8<!X3O>(v);  // four chains: one wave per SIMD has no partner to fill VALU gaps
+                                                                        // (X3O keeps hi + lo of the value: the fp32-grade degree-11 set)
                 V8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = Op<T>::from(v[e]);
                 const int m = m_base + RR * i + r, n = nb + 8 * c8;
+                if constexpr (X3O) {
+                    if (FULL || (m < p.M && n < p.N)) {
+                        V8 lo;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) lo[e] = Op<T>::from(v[e] - Op<T>::to(o[e]));
+                        T* q = out + (size_t)m * (3 * (size_t)p.N) + (size_t)(n >> 6) * 192 + (n & 63);
+                        *reinterpret_cast<V8*>(q) = o;
+                        *reinterpret_cast<V8*>(q + 64) = o;
+                        *reinterpret_cast<V8*>(q + 128) = lo;
+                    }
+                } else
                 if (FULL || (m < p.M && n < p.N)) {
                     if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<V8*>(out + (size_t)m * p.N + n));
                     else *reinterpret_cast<V8*>(out + (size_t)m * p.N + n) = o;
@@ -437,8 +451,10 @@ ESMK_DEV void epilogue9_t(const GemmArgs& p, f32x4 (&acc)[8][NMI], int m_base, i
 // slots; every output element sees the same MFMA sequence over K as in the full-height kernel: same bits.
 // LNF: LayerNorm fold (kernels.h): EPI_RESID_F32 = producer (second operand-dtype output + row statistics),
 // EPI_QKV_ROPE / EPI_V_T / EPI_GELU_T = consumer (accumulators start from 0, row scale + bias in the epilogue).
-template <typename T, int EPI, int VAR = 0, bool HM = false, bool LNF = false>
+// X3O: EPI_GELU_T with hi | hi | lo output rows (precision mode f16x3; an instantiation of its own, full height)
+template <typename T, int EPI, int VAR = 0, bool HM = false, bool LNF = false, bool X3O = false>
 __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long long* timing) {
+    static_assert(!X3O || (EPI == EPI_GELU_T && !HM && !LNF && VAR == 0), "hi | hi | lo output rows: plain full-height GELU kernel");
     static_assert(!LNF || EPI == EPI_RESID_F32 || EPI == EPI_QKV_ROPE || EPI == EPI_V_T || EPI == EPI_GELU_T || EPI == EPI_QKV_ALL,
                   "LayerNorm fold: epilogue");
     constexpr bool LNC = LNF && EPI != EPI_RESID_F32;  // consumer
@@ -888,8 +904,8 @@ __global__ __launch_bounds__(256, 1) void gemm9_kernel(GemmArgs p, unsigned long
                 else epilogue9_t<T, EPI_QKV_ROPE, false, NTS, NMI, HM ? 16 : 32, LNF>(p, acc, m_base, n_base, lane, slice);
             }
         } else {
-            if (full) epilogue9_t<T, EPI, true, NTS, NMI, HM ? 16 : 32, LNF>(p, acc, m_base, n_base, lane, slice);
-            else epilogue9_t<T, EPI, false, NTS, NMI, HM ? 16 : 32, LNF>(p, acc, m_base, n_base, lane, slice);
+            if (full) epilogue9_t<T, EPI, true, NTS, NMI, HM ? 16 : 32, LNF, X3O>(p, acc, m_base, n_base, lane, slice);
+            else epilogue9_t<T, EPI, false, NTS, NMI, HM ? 16 : 32, LNF, X3O>(p, acc, m_base, n_base, lane, slice);
         }
         if constexpr (!BIAS_EARLY) next_bias();
         stamp(it, 2);
@@ -915,10 +931,10 @@ static int num_workgroups9() {
     return n;
 }
 
-template <typename T, int EPI, int VAR = 0, bool HM = false, bool LNF = false>
+template <typename T, int EPI, int VAR = 0, bool HM = false, bool LNF = false, bool X3O = false>
 static hipError_t launch9(GemmArgs p, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = gemm9_kernel<T, EPI, VAR, HM, LNF>;
+    auto kern = gemm9_kernel<T, EPI, VAR, HM, LNF, X3O>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
@@ -990,6 +1006,12 @@ static hipError_t dispatch9(const GemmArgs& p, int epi, int var, hipStream_t st)
         }
     }
 #endif
+    if (p.x3_out) {  // f16x3: fc1 + GELU with hi | hi | lo output rows — full height, fp16
+        if constexpr (std::is_same<T, _Float16>::value) {
+            if (epi == EPI_GELU_T && var == 0 && !gemm9_ln_fold(p, epi)) return launch9<T, EPI_GELU_T, 0, false, false, true>(p, st);
+        }
+        return hipErrorInvalidValue;
+    }
     if (gemm9_ln_fold(p, epi)) {  // LayerNorm fold: producer / consumer forms of the four epilogues, both tile heights
         if (var != 0) return hipErrorInvalidValue;
         if (epi == EPI_RESID_F32 && (p.h16 == nullptr || p.ln_mean == nullptr || p.ldh < p.N || p.ln_parts < (p.N + 127) / 128))

@@ -74,6 +74,9 @@ struct GemmArgs {
     const float* ln_mean = nullptr;
     const float* ln_rstd = nullptr;
     const float* bias2 = nullptr;
+    // Precision mode f16x3, EPI_GELU_T: the output rows leave as the A operand of that mode's fc2 — per 64-column K tile
+    // hi | hi | lo, lo = T(v - T(v)), row stride 3 N; full-height gemm9 instantiation of its own
+    int x3_out = 0;
     int lnf_dbg = 0;  // timing experiments on the producer (results incomplete): 1 no h16 stores, 2 no statistics, 4 no mean loads
     // gemm9, EPI_RESID_F32: start-up delay (shader cycles) of one workgroup group — takes the HBM-bound read-modify-write
     // epilogues of the two groups out of lockstep (set by launch_gemm; 0 = none).  desync_group: 0 = odd XCDs are late,
@@ -138,6 +141,7 @@ struct LnExtra {
     const float* row_keep = nullptr;
     int map_R = 0, map_C = 0;
     int ldy = 0;  // row stride of the operand-dtype output in elements (0 = E): K-padded activation rows
+    int x3 = 0;   // precision mode f16x3: y rows in the hi | hi | lo layout per 64-column K tile (ldy >= 3 E), lo = T(o - T(o))
 };
 hipError_t launch_layernorm_ex(const float* x, const float* gamma, const float* beta, void* y,
                                float* y32, int rows, int E, int operand_dtype, LnExtra ex,
@@ -160,10 +164,9 @@ hipError_t launch_convert2d(const void* src, int src_dtype, void* dst, int dst_d
 // becomes hi = fp16(w) at dst[r][128 t .. +63] and lo = fp16(w - hi) at dst[r][128 t + 64 .. +127]
 // (hi + lo carries ~19-22 bits of w: the MFMA takes fp16 subnormals as they are); row_map / col_map as above
 // parts = 3 (operand mode f16x3): hi | lo | hi per K tile, rows of 3 dst_ld — against activation rows hi | hi | lo
-// (launch_split3_rows, attention's X3 output) a plain GEMM over K' = 3 K is A_hi W_hi + A_hi W_lo + A_lo W_hi
+// (LnExtra::x3, GemmArgs::x3_out, attention's X3 output) a plain GEMM over K' = 3 K is A_hi W_hi + A_hi W_lo + A_lo W_hi
 hipError_t launch_convert2d_split(const void* src, int src_dtype, void* dst, size_t rows, size_t cols, size_t dst_ld,
                                   int row_map, int col_map, int d, hipStream_t st, int parts = 2);
-hipError_t launch_split3_rows(const float* src, void* dst, size_t rows, int cols, size_t src_ld, size_t dst_ld, hipStream_t st);
 // RoPE tables cos/sin[t][i] = cos/sin(t * inv_freq[i]) (rotary_embedding.py:47-61), fp32
 hipError_t launch_rope_table(const float* inv_freq, float* cos, float* sin, int T, int half,
                              hipStream_t st);
