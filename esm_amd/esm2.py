@@ -100,7 +100,7 @@ def _weight_split():
     ``ESM_AMD_OPERAND=f16x2v``: the VALUE path only (v, out: a sixth of the GEMM work, ~1.2x) — most of f16x2a's gain on
     representations and logits; q / k rounding matters for the attention maps / contact logits only.
     ``ESM_AMD_OPERAND=f16x3``: weights AND GEMM inputs split (every layer GEMM a plain launch over K' = 3 K: A_hi W_hi +
-    A_hi W_lo + A_lo W_hi) — the mode that holds 1e-3 on EVERY output, contact logits included, at ~3x the step;
+    A_hi W_lo + A_lo W_hi) — the mode that holds 1e-3 on EVERY output, contact logits included, at ~2.4x the step;
     head_dim-64 models, padded batches (``forward_varlen`` falls back to ``forward``).
     Returns esmk_config.weight_split: 0 off, 1 f16x2, 2 f16x2a, 3 f16x2v, 4 f16x3."""
     env = os.environ.get("ESM_AMD_OPERAND", "").lower()
