@@ -78,7 +78,7 @@ typedef struct esmk_config {
      * 4 = "f16x3": weights AND GEMM inputs split — every matrix is packed hi | lo | hi per 64-column K tile and every layer
      * GEMM runs as a plain launch over K' = 3 K on operand rows hi | hi | lo (A_hi W_hi + A_hi W_lo + A_lo W_hi); only q / k, v
      * and P of the attention stay fp16.  Representations, logits AND contact logits inside 1e-3 of the reference
-     * (tests/test_readme.py:116 atol) at ~2.65x the step.  head_dim 64, embed_dim % 64 == 0, padded batches (esmk_forward). */
+     * (tests/test_readme.py:116 atol) at ~2.4x the step.  head_dim 64, embed_dim % 64 == 0, padded batches (esmk_forward). */
     int32_t weight_split;
     /* LayerNorm fold (reference esm/modules.py:120-140, the two LayerNorm -> Linear pairs of a TransformerLayer): 1 = the
      * q/k/v and fc1 weights are packed multiplied by the LayerNorm weight and row-centred, the residual GEMMs emit the
