@@ -518,11 +518,10 @@ SECONDARY = [  # --quick-baseline: the children's own CPU-oracle sample (parity 
     # qk_gain 4 (row maximum 0.68; what VERDICT r5 named) is timed in the same child, without parity (its floor is 0.47)
     ("esm2_650m_sharp", ["--workload", "esm2_650m", "--steps", "10", "--warmup", "3", "--no-secondary", "--quick-baseline",
                          "--qk-gain", "2.5", "--ln-gamma-std", "0.1", "--also-qk-gain", "4"], 100),
-    # the headline configuration and the B = 4 line WITHOUT the LayerNorm fold (round 4's default path), same run, same box
+    # the headline configuration WITHOUT the LayerNorm fold (round 4's default path), same run, same box
+    # (the B = 4 plain-mode line of round 5 left the default run in round 6: eight children, ~4 min on a slow host)
     ("esm2_650m_plain", ["--workload", "esm2_650m", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-secondary",
                          "--ln-fold", "0", "--parity-ref", "{PARITY_REF}"], 90),
-    ("esm2_650m_b4_plain", ["--workload", "esm2_650m", "--batch", "4", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
-                            "--no-secondary", "--ln-fold", "0", "--parity-ref", "{PARITY_REF}"], 60),
 ]
 T_PROCESS_START = time.perf_counter()
 SECONDARY_BUDGET_S = 270.0  # the default run, children included, ends within ~4.5 minutes of its start (eight children: ~165 s)
