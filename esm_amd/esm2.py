@@ -114,6 +114,33 @@ def _ln_fold():
     return 0 if v == "" else (1 if v not in ("0", "off", "false") else -1)
 
 
+# The LayerNorm fold and small LayerNorm gains (round 6, tools/outlier_stress_study.py, profiles/r6_outlier_stress_study.log).
+# The fold's consumers run on gain-folded, row-centred weight images: column j of an image holds gamma_j w_ij - c_i with
+# c_i = mean_k(gamma_k w_ik), and its operand rows are the un-normalised fp16(x - mean).  A channel whose gain is far below
+# the others (|gamma_j| << median / sqrt(E)) holds almost nothing but -c_i; if the checkpoint uses that small gain to silence
+# a large activation (the "massive activation" channels of trained transformers), the fp16 rounding of x_j and of c_i is
+# multiplied by that large x_j: the fold's error grows with x_j / (E s) (s: the spread of the ordinary channels) while the
+# plain mode — which rounds the normalised value gamma_j (x_j - mean) rstd — does not see the channel at all.  Measured on
+# the stress weights of esm_amd.synth.add_outlier_channels (650M dims, four channels): gain ratio 133 (outliers 200 x the
+# stream) -> fold / plain floor 1.1; 1333 -> 3.3 ... 4.2; 13333 -> 34.  The hazard of one LayerNorm, from its gains alone:
+#     h = sum over channels with |gamma_j| < median / 8 of (median / |gamma_j|) / E
+# and of a model: the mean over its folded LayerNorms (0.35 / 3.5 / 35 on those three sets; the stream of the first layers
+# is small, so their ratios are the largest).  When ESM_AMD_LN_FOLD is unset, a model whose h exceeds 0.5 runs WITHOUT the
+# fold (the standalone LayerNorm passes:
+# - 1.1 % at B = 64, - 6 % at B = 4); ESM_AMD_LN_FOLD=1 forces it on, =0 off.  Callers of the C ABI choose esmk_config.ln_fold
+# themselves.
+_FOLD_HAZARD_MAX = 0.5
+
+
+def ln_fold_hazard(gains):
+    """``gains``: [n_layernorms, E] LayerNorm weights whose outputs feed folded GEMMs.  Returns their mean h (see above)."""
+    g = gains.detach().float().abs()
+    med = g.median(dim=-1, keepdim=True).values
+    small = g < med / 8
+    h = torch.where(small, med / g.clamp_min(1e-30), torch.zeros_like(g)).sum(-1) / g.shape[-1]
+    return float(h.mean().item()) if h.numel() else 0.0
+
+
 # Small and medium batches as TWO half-batches on two HIP streams (round 6).  Below ~56 k rows the persistent GEMMs end in
 # partly filled rounds of tiles over the 256 CUs (B = 8 x 1024 tokens: fc2 has 320 half-height tiles = 1.25 rounds);
 # workgroups without a tile exit at once, so the kernels of a second, independent half-batch take the idle CUs.  Measured on
@@ -195,14 +222,15 @@ def warn_if_grad_expected(model):
 class _Engine:
     """One esmk_model handle + packed parameter image + workspace for one (device, dtype)."""
 
-    def __init__(self, model: "ESM2", device, operand_dtype, weight_split=0):
+    def __init__(self, model: "ESM2", device, operand_dtype, weight_split=0, ln_fold=None):
         from . import _native as N
 
         self.N = N
         self.device = device
         self.operand_dtype = operand_dtype
         self.weight_split = int(weight_split)  # esmk_config.weight_split: 0 off, 1 f16x2, 2 f16x2a, 3 f16x2v
-        self.ln_fold = _ln_fold()  # ESM_AMD_LN_FOLD at creation: a changed setting makes a new engine
+        # ESM_AMD_LN_FOLD (or the gain check of ESM2._fold_setting) at creation: a changed setting makes a new engine
+        self.ln_fold = _ln_fold() if ln_fold is None else int(ln_fold)
         # ESM-1b / ESM-1v (esm_amd.esm1.ProteinBertModel) set these; ESM-2 leaves them at zero
         self.no_rope = int(getattr(model, "_engine_no_rope", 0))
         num_positions = int(getattr(model, "_engine_num_positions", 0))
@@ -266,7 +294,8 @@ class _Engine:
         named = live_tensors(self, model, skip=lambda k: k == "lm_head.weight" or k.endswith("inv_freq"))
         fp = tuple((id(t), t.data_ptr(), t._version, t.dtype) for _, t in named)
         if fp == self.fingerprint:
-            return
+            return False
+        repacked = self.fingerprint is not None  # (the first pack of a new engine is not a change of the parameters)
         stream = N.cur_stream()
         # LayerNorm parameters first: with the LayerNorm fold the q/k/v and fc1 weights are folded with them at pack time
         for key, t in sorted(named, key=lambda kt: 0 if "layer_norm" in kt[0] else 1):
@@ -278,6 +307,7 @@ class _Engine:
                                            key.encode(), N.ptr(t), N.dtype_code(t.dtype), shape, t.dim(),
                                            stream))
         self.fingerprint = fp
+        return repacked
 
     def workspace_for(self, B, T, flags):
         N = self.N
@@ -333,13 +363,41 @@ class ESM2(nn.Module):
         pdt = self.embed_tokens.weight.dtype
         odt = _operand_dtype_for(pdt)
         split = _weight_split()
+        fold = self._fold_setting()
         eng = self._engine
         if (eng is None or eng.device != device or eng.operand_dtype != odt or eng.weight_split != split
-                or eng.ln_fold != _ln_fold()):
+                or eng.ln_fold != fold):
             if eng is not None:
                 eng.close()
-            eng = _Engine(self, device, odt, split)
+            eng = _Engine(self, device, odt, split, fold)
             object.__setattr__(self, "_engine", eng)
+        return eng
+
+    def _fold_setting(self):
+        """esmk_config.ln_fold for this model: ESM_AMD_LN_FOLD when set; otherwise 0 (the library's default: on where it is
+        supported) unless the LayerNorm gains in front of the q/k/v and fc1 projections make the fold's operand form lossy
+        (``ln_fold_hazard`` above) — then -1.  The gains are read when the engine's parameter fingerprint changes
+        (``_engine_ready``), not per call."""
+        env = _ln_fold()
+        if env != 0:
+            return env
+        h = self.__dict__.get("_fold_hazard")
+        if h is None:
+            gains = [l.weight.detach() for layer in self.layers for l in (layer.self_attn_layer_norm, layer.final_layer_norm)]
+            h = ln_fold_hazard(torch.stack(gains)) if gains else 0.0
+            object.__setattr__(self, "_fold_hazard", h)
+        return -1 if h > _FOLD_HAZARD_MAX else 0
+
+    def _engine_ready(self, device):
+        """The engine for this call with the current parameters packed.  Changed parameters (``_Engine.sync_weights``) may have
+        changed the LayerNorm gains: the fold decision is taken again, and an engine of the other mode is made if it flipped."""
+        eng = self._get_engine(device)
+        if eng.sync_weights(self) and _ln_fold() == 0:
+            object.__setattr__(self, "_fold_hazard", None)
+            again = self._get_engine(device)
+            if again is not eng:
+                again.sync_weights(self)
+            eng = again
         return eng
 
     def forward(self, tokens, repr_layers=[], need_head_weights=False, return_contacts=False, contacts_only=False):
@@ -367,8 +425,7 @@ class ESM2(nn.Module):
         L, E, H, V = self.num_layers, self.embed_dim, self.attention_heads, self.alphabet_size
         repr_set = sorted({int(i) for i in repr_layers if 0 <= int(i) <= L})
         with torch.cuda.device(dev):
-            eng = self._get_engine(dev)
-            eng.sync_weights(self)
+            eng = self._engine_ready(dev)
             tok = tokens.to(torch.int64).contiguous()
             # predict_contacts: no logits, no attention tensor (contacts.hip accumulates the map layer by layer)
             flags = 0 if contacts_only else N.OUT_LOGITS
@@ -474,8 +531,7 @@ class ESM2(nn.Module):
             return self.forward(tokens.to(dev), repr_layers=repr_layers)  # (f16x3 has no token-packed form)
         repr_set = sorted({int(i) for i in repr_layers if 0 <= int(i) <= L})
         with torch.cuda.device(dev):
-            eng = self._get_engine(dev)
-            eng.sync_weights(self)
+            eng = self._engine_ready(dev)
             idx, keep = plan.index(dev)
             flat = plan.pack(tokens, self.padding_idx, idx)
             f32 = dict(dtype=torch.float32, device=dev)
@@ -532,6 +588,7 @@ class ESM2(nn.Module):
         if self._engine is not None:
             self._engine.close()
         object.__setattr__(self, "_engine", None)
+        object.__setattr__(self, "_fold_hazard", None)
 
     def __getstate__(self):
         state = self.__dict__.copy()

@@ -111,6 +111,56 @@ def synth_esm2_state_dict(num_layers, embed_dim, heads, seed=0, qk_gain=2.0, dev
     return sd
 
 
+def add_outlier_channels(sd, num_layers, embed_dim, channels=4, magnitude=200.0, token_spread=10.0, seed=0, balanced=False):
+    """The "stress" weight set of SURVEY.md §7.4: large-magnitude outlier channels in the residual stream, to approximate the
+    dynamic range of a trained checkpoint (a few channels hundreds of times the rest, LayerNorm gains that undo them).
+    In place on an ESM-2 state dict of ``synth_esm2_state_dict``; returns the channel indices.
+
+    * layer 0's ``fc2`` writes ``+-magnitude`` into ``channels`` seeded channels through its bias (the same for every token)
+      and ``token_spread`` times its usual weight rows (different for every token); every later layer's out-projection and
+      ``fc2`` keep writing into those channels at ``token_spread`` times the usual scale, so the outliers move with depth;
+    * the outliers add ``channels * magnitude^2 / E`` to a row's variance.  Every LayerNorm that sees them gets its gains
+      multiplied by sqrt(1 + that / s^2) on the ordinary channels — s(p)^2 = 0.22 p^1.1 is the variance of the ordinary
+      stream of these synthetic weights at depth p (measured: 0.468, 0.963, 1.43, 2.15, 3.13 at p = 1, 4, 8, 16, 32 for every
+      width) — so that the normalised ordinary channels keep the scale they have without the outliers (the network stays
+      as sharp and as non-chaotic as the plain synthetic one), and set so that the normalised outliers come out near 1: a
+      gain spread of about magnitude / s : 1 inside one LayerNorm, as trained checkpoints have.  Three outliers point up
+      and one down, so the row mean moves by magnitude / 2 / E * 4 / channels...; the LayerNorm biases of the ordinary
+      channels take that shift back."""
+    g = torch.Generator()
+    g.manual_seed(0x5EED ^ seed)
+    idx = torch.randperm(embed_dim, generator=g)[:channels].sort().values
+    # three up, one down: the row mean moves too (by magnitude / 640 at E = 1280) and the LayerNorm biases take that back;
+    # balanced: two up, two down — the same outliers without a common offset of the ordinary channels
+    sign = torch.where(torch.arange(channels) % 2 == 1, -1.0, 1.0) if balanced else torch.where(torch.arange(channels) % 4 == 3, -1.0, 1.0)
+    dev = sd["layers.0.fc2.bias"].device
+    idx_d = idx.to(dev)
+    sd["layers.0.fc2.bias"][idx_d] = (sign * magnitude).to(dev)
+    for i in range(num_layers):
+        sd[f"layers.{i}.fc2.weight"][idx_d] *= token_spread
+        if i > 0:
+            sd[f"layers.{i}.self_attn.out_proj.weight"][idx_d] *= token_spread
+    out_var = channels * magnitude ** 2 / embed_dim
+
+    mean_shift = float(sign.sum()) * magnitude / embed_dim  # what the constant part of the outliers adds to a row's mean
+
+    def regain(name, depth):
+        s2 = 0.22 * depth ** 1.1
+        w, b = sd[name + ".weight"], sd[name + ".bias"]
+        row_std = (out_var - mean_shift ** 2 + s2) ** 0.5
+        w *= row_std / s2 ** 0.5
+        w[idx_d] = w[idx_d] * (s2 ** 0.5 / magnitude)
+        keep = b[idx_d].clone()
+        b += w * (mean_shift / row_std)  # the ordinary channels' (x - mean) / std * gain is lower by exactly this
+        b[idx_d] = keep
+
+    for i in range(1, num_layers):  # layer 0's two LayerNorms come before the first outlier is written
+        regain(f"layers.{i}.self_attn_layer_norm", i)
+        regain(f"layers.{i}.final_layer_norm", i + 0.5)
+    regain("emb_layer_norm_after", num_layers)
+    return idx
+
+
 def synth_tokens(batch, length, seed=1, device="cpu"):
     """BASELINE synthetic batch: <cls> + `length` uniform ids in 4..23 + <eos> (SURVEY §8 d)."""
     g = torch.Generator()

@@ -387,3 +387,37 @@ def test_environment_switches_of_the_python_engine(monkeypatch):
     monkeypatch.setenv("ESM_AMD_DUAL_STREAM", "100:200,1000:2000")
     assert esm2._dual_stream_window() == [(100, 200), (1000, 2000)]
     assert esm2._dual_stream_wanted(150) and esm2._dual_stream_wanted(2000) and not esm2._dual_stream_wanted(500)
+
+
+def test_ln_fold_is_not_chosen_for_checkpoints_with_small_layernorm_gains(monkeypatch):
+    """ESM2._fold_setting (round 6): ESM_AMD_LN_FOLD wins when set; unset, the LayerNorm gains decide — esmk_config.ln_fold 0
+    (library default: fold on) for the plain synthetic weights and for the stress set with outliers 200 x the stream (gain
+    ratio 133: fold / plain floor 1.1, profiles/r6_outlier_stress_study.log), -1 (fold off) from gain ratio ~ 200 on (2000 x:
+    fold floor 3.3 x the plain one)."""
+    import esm
+    from esm_amd import esm2
+    from esm_amd.synth import add_outlier_channels, skip_param_init, synth_esm2_state_dict
+
+    monkeypatch.delenv("ESM_AMD_LN_FOLD", raising=False)
+    L, E, H = 33, 320, 20  # a quarter of the 650M width: the same h at a quarter of the outlier magnitude
+    with skip_param_init():
+        model = esm.ESM2(L, E, H).eval()
+    want = {0.0: (0, 0.0, 0.0), 50.0: (0, 0.3, 0.5), 500.0: (-1, 3.0, 5.0), 5000.0: (-1, 30.0, 50.0)}
+    for mag, (setting, lo, hi) in want.items():
+        sd = synth_esm2_state_dict(L, E, H, seed=0)
+        if mag:
+            add_outlier_channels(sd, L, E, magnitude=mag)
+        model.load_state_dict(sd)
+        model.refresh_engine()  # (on a GPU the engine's parameter fingerprint does this: ESM2._engine_ready)
+        assert model._fold_setting() == setting, mag
+        h = model._fold_hazard
+        assert lo <= h <= hi, (mag, h)
+    monkeypatch.setenv("ESM_AMD_LN_FOLD", "1")
+    assert model._fold_setting() == 1
+    monkeypatch.setenv("ESM_AMD_LN_FOLD", "0")
+    assert model._fold_setting() == -1
+    # a zero gain (a pruned channel) is a small gain
+    g = torch.ones(2, 64)
+    assert esm2.ln_fold_hazard(g) == 0.0
+    g[1, 5] = 0.0
+    assert esm2.ln_fold_hazard(g) > 1e6

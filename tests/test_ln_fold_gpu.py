@@ -297,3 +297,44 @@ def test_fold_pack_order_is_enforced():
     # weight_split and the fold exclude each other
     cfg = N.EsmkConfig(L, E, H, 4 * E, 33, 1, 32, 0, 2, 1, 1, 1, 1, 0, 0, 0, 1, 1)
     assert N.lib.esmk_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+
+
+def test_gain_check_follows_the_parameters(monkeypatch):
+    """ESM2._engine_ready (round 6): with ESM_AMD_LN_FOLD unset the package leaves the fold off for checkpoints whose LayerNorm
+    gains silence large channels (esm_amd/esm2.py ln_fold_hazard) — decided on the CURRENT parameters: loading such weights
+    into a model that has already run makes an engine of the other mode, loading ordinary ones brings the fold back; either
+    way the outputs are those of a fresh model with the same weights, bit for bit.  ESM_AMD_LN_FOLD=1 overrides the check."""
+    from esm_amd.synth import add_outlier_channels
+
+    monkeypatch.delenv("ESM_AMD_LN_FOLD", raising=False)
+    L, E, H = 3, 128, 2
+    plain_sd = synth_esm2_state_dict(L, E, H, seed=4)
+    stress_sd = synth_esm2_state_dict(L, E, H, seed=4)
+    add_outlier_channels(stress_sd, L, E, magnitude=300.0)
+    toks = synth_tokens(2, 30, seed=9).cuda()
+
+    def fresh(sd):
+        with skip_param_init():
+            m = esm.ESM2(L, E, H).eval()
+        m.load_state_dict(sd)
+        return m.cuda()
+
+    with torch.no_grad():
+        model = fresh(plain_sd)
+        a = model(toks, repr_layers=[L])
+        assert model.ln_fold_active() is True and model._fold_hazard == 0.0
+        model.load_state_dict(stress_sd)
+        b = model(toks, repr_layers=[L])
+        assert model.ln_fold_active() is False and model._fold_hazard > 0.5
+        ref = fresh(stress_sd)
+        rb = ref(toks, repr_layers=[L])
+        assert ref.ln_fold_active() is False
+        assert torch.equal(b["logits"], rb["logits"]) and torch.equal(b["representations"][L], rb["representations"][L])
+        model.load_state_dict(plain_sd)
+        c = model(toks, repr_layers=[L])
+        assert model.ln_fold_active() is True
+        assert torch.equal(c["logits"], a["logits"]) and torch.equal(c["representations"][L], a["representations"][L])
+        monkeypatch.setenv("ESM_AMD_LN_FOLD", "1")
+        model.load_state_dict(stress_sd)
+        model(toks, repr_layers=[L])
+        assert model.ln_fold_active() is True

@@ -137,6 +137,68 @@ def test_650m_dims_against_oracle(B, T, padded):
     C.check_raw_argmax(f"650M-dims B={B} T={T} token argmax", raw, C.raw_argmax_agreement(floor["logits"], ref["logits"], nonpad))
 
 
+@pytest.mark.parametrize("magnitude,force_fold", [(200.0, False), (2000.0, False), (2000.0, True)])
+def test_650m_dims_outlier_channels_against_oracle(monkeypatch, magnitude, force_fold):
+    """The stress weight set: four residual channels at +-magnitude — 100 ... 1000 x the ordinary
+    stream — written by layer 0's fc2 and moved by every later layer, LayerNorm gains that silence them (a spread of 60 ...
+    4000 : 1, esm_amd.synth.add_outlier_channels).  What it stresses: the LayerNorm fold's un-normalised fp16 operand rows
+    fp16(x - mean) and gain-folded, row-centred weight images, the partial-sum statistics next to values 1000 x larger, the
+    fp32 residual epilogues.  The fold's floor grows with the outliers (column j of an image is gamma_j w_ij - c_i: a silenced
+    channel holds the centring constant alone, times a large x_j; tools/outlier_stress_study.py): 1.1 x the plain floor at
+    200, 3.3 x at 2000.  So: at 200 the default runs the fold and meets the contract; at 2000 the package's gain check
+    (esm_amd/esm2.py ln_fold_hazard) leaves the fold off and the plain mode meets it on the plain floor, which the outliers do
+    not move; and the fold forced on at 2000 sits on ITS floor — the engine is its form's floor even there.
+    Floor-referenced in both norms, on all channels and on the ordinary channels alone."""
+    from esm_amd.synth import add_outlier_channels
+
+    L, E, H = 33, 1280, 20
+    sd = synth_esm2_state_dict(L, E, H, seed=0)
+    idx = add_outlier_channels(sd, L, E, magnitude=magnitude)
+    with skip_param_init():
+        model = esm.ESM2(L, E, H).eval()
+    model.load_state_dict(sd)
+    model = model.cuda()
+    if force_fold:
+        monkeypatch.setenv("ESM_AMD_LN_FOLD", "1")
+    env = os.environ.get("ESM_AMD_LN_FOLD", "")
+    toks = synth_tokens(2, 254, seed=1)
+    toks[1, 100] = 2
+    toks[1, 101:] = 1
+    with torch.no_grad():
+        out = model(toks.cuda(), repr_layers=[1, 16, 33], return_contacts=True)
+    if env == "":  # the gain check decides
+        assert model.ln_fold_active() == (magnitude < 1000), (magnitude, model._fold_hazard)
+    else:
+        assert model.ln_fold_active() == (env == "1")
+    ref = esm2_forward(sd, toks, L, H, repr_layers=[1, 16, 33], return_contacts=True)
+    floor = C.floor_forward(sd, toks, L, H, model=model, repr_layers=[1, 16, 33], return_contacts=True)
+    nonpad = toks.ne(1)
+    ordinary = torch.ones(E, dtype=torch.bool)
+    ordinary[idx] = False
+    r16 = ref["representations"][16][nonpad]
+    tag = f"650M-dims outliers {magnitude:g}{' fold forced' if force_fold else ''}"
+    print(f"\n{tag}: channels {idx.tolist()}, |x| at layer 16 {[round(v) for v in r16[:, idx].abs().mean(0).tolist()]}, "
+          f"ordinary std {r16[:, ordinary].std().item():.2f}, fold {'on' if model.ln_fold_active() else 'off'}")
+    assert r16[:, idx].abs().mean() > 50 * r16[:, ordinary].std()
+    for l in (1, 16, 33):
+        C.check_tensors(f"{tag} repr[{l}]", out["representations"][l].cpu(), ref["representations"][l],
+                        floor["representations"][l], nonpad, deep=True)
+        C.check_tensors(f"{tag} repr[{l}] ordinary channels", out["representations"][l].cpu()[..., ordinary],
+                        ref["representations"][l][..., ordinary], floor["representations"][l][..., ordinary], nonpad, deep=True)
+    C.check_tensors(f"{tag} logits", out["logits"].cpu(), ref["logits"], floor["logits"], nonpad, deep=True)
+    raw, decided_ok, _ = argmax_agreement(out["logits"].cpu(), ref["logits"], nonpad)
+    assert decided_ok
+    C.check_raw_argmax(f"{tag} token argmax", raw, C.raw_argmax_agreement(floor["logits"], ref["logits"], nonpad))
+    c, cr, cf = out["contacts"].cpu(), ref["contacts"], floor["contacts"]
+    for b, sl in ((0, slice(None)), (1, slice(0, 99))):
+        _, zrel = C.contact_logit_errors(c[b, sl, sl], cr[b, sl, sl])
+        _, zfl = C.contact_logit_errors(cf[b, sl, sl], cr[b, sl, sl])
+        C.check(f"{tag} contact logits seq {b}", zrel, zrel, zfl, zfl, slack=C.CONTACT_SLACK, slack_l2=C.CONTACT_SLACK)
+    if not model.ln_fold_active():  # the plain mode does not see the outliers: the deep-stack contract as without them
+        l2, _ = C.errors(out["representations"][33].cpu(), ref["representations"][33], nonpad)
+        assert l2 <= 1e-3, l2
+
+
 def test_3b_dims_contacts_against_oracle():
     """BASELINE configs[2] dimensions (36 x 2560 x 40 heads): contact-head parity vs CPU."""
     L, E, H = 36, 2560, 40
