@@ -50,13 +50,21 @@ def config_for(m, operand_dtype=torch.float16, weight_split=0, ln_fold=0):
                   int(bool(m.append_eos)), _DTYPE[operand_dtype], 0, 0, 0, int(weight_split), int(ln_fold))
 
 
+def gain_hazard(m):
+    """The check INTEGRATION.md asks of a binding before esmk_create: LayerNorm gains that silence very large channels make
+    the fold's un-normalised fp16 operand rows lossy -> run such checkpoints with ln_fold = -1."""
+    g = torch.stack([ln.weight.detach().float().abs() for layer in m.layers for ln in (layer.self_attn_layer_norm, layer.final_layer_norm)])
+    med = g.median(dim=-1, keepdim=True).values
+    return float((torch.where(g < med / 8, med / g.clamp_min(1e-30), torch.zeros_like(g)).sum(-1) / g.shape[-1]).mean())
+
+
 class Engine:
     """One esmk_model handle + packed parameter image + workspace for a model on one device."""
 
     def __init__(self, m, device, operand_dtype=torch.float16):
         L = lib()
         self.device, self.h = device, ctypes.c_void_p()
-        cfg = config_for(m, operand_dtype)
+        cfg = config_for(m, operand_dtype, ln_fold=-1 if gain_hazard(m) > 0.5 else 0)
         with torch.cuda.device(device):
             _chk(L.esmk_create(ctypes.byref(cfg), ctypes.byref(self.h)))
             d = m.embed_dim // m.attention_heads
