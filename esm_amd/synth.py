@@ -113,7 +113,7 @@ def synth_esm2_state_dict(num_layers, embed_dim, heads, seed=0, qk_gain=2.0, dev
 
 def add_outlier_channels(sd, num_layers, embed_dim, channels=4, magnitude=200.0, token_spread=10.0, seed=0, balanced=False):
     """The "stress" weight set of SURVEY.md §7.4: large-magnitude outlier channels in the residual stream, to approximate the
-    dynamic range of a trained checkpoint (a few channels hundreds of times the rest, LayerNorm gains that undo them).
+    dynamic range a trained checkpoint may have (a few channels hundreds of times the rest, LayerNorm gains that undo them).
     In place on an ESM-2 state dict of ``synth_esm2_state_dict``; returns the channel indices.
 
     * layer 0's ``fc2`` writes ``+-magnitude`` into ``channels`` seeded channels through its bias (the same for every token)
@@ -124,9 +124,10 @@ def add_outlier_channels(sd, num_layers, embed_dim, channels=4, magnitude=200.0,
       stream of these synthetic weights at depth p (measured: 0.468, 0.963, 1.43, 2.15, 3.13 at p = 1, 4, 8, 16, 32 for every
       width) — so that the normalised ordinary channels keep the scale they have without the outliers (the network stays
       as sharp and as non-chaotic as the plain synthetic one), and set so that the normalised outliers come out near 1: a
-      gain spread of about magnitude / s : 1 inside one LayerNorm, as trained checkpoints have.  Three outliers point up
-      and one down, so the row mean moves by magnitude / 2 / E * 4 / channels...; the LayerNorm biases of the ordinary
-      channels take that shift back."""
+      gain spread of about magnitude / s : 1 inside one LayerNorm.  Of every four outliers three point up and one down
+      (``balanced``: two and two), so the row mean moves by sum(sign) * magnitude / E; the LayerNorm biases of the
+      ordinary channels take that shift back.  Whether trained checkpoints look like this cannot be checked offline: the
+      set is a stress case for the engine's operand forms, not a model of one."""
     g = torch.Generator()
     g.manual_seed(0x5EED ^ seed)
     idx = torch.randperm(embed_dim, generator=g)[:channels].sort().values
