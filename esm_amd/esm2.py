@@ -120,7 +120,9 @@ def _ln_fold():
 # the others (|gamma_j| << median / sqrt(E)) holds almost nothing but -c_i; if the checkpoint uses that small gain to silence
 # a large activation (the "massive activation" channels of trained transformers), the fp16 rounding of x_j and of c_i is
 # multiplied by that large x_j: the fold's error grows with x_j / (E s) (s: the spread of the ordinary channels) while the
-# plain mode — which rounds the normalised value gamma_j (x_j - mean) rstd — does not see the channel at all.  Measured on
+# plain mode — which rounds the normalised value gamma_j (x_j - mean) rstd — does not see the channel at all.  (Same-signed
+# outliers add a second term: they shift the row mean, the LayerNorm bias takes the shift back — exactly, as fp32 W . beta, in
+# the fold, against a counterpart that went through the rounded image)  Measured on
 # the stress weights of esm_amd.synth.add_outlier_channels (650M dims, four channels): gain ratio 133 (outliers 200 x the
 # stream) -> fold / plain floor 1.1; 1333 -> 3.3 ... 4.2; 13333 -> 34.  The hazard of one LayerNorm, from its gains alone:
 #     h = sum over channels with |gamma_j| < median / 8 of (median / |gamma_j|) / E

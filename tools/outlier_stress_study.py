@@ -6,14 +6,20 @@ against the fp32 oracle (test infrastructure) and the fp16-operand floor in the 
 
 What it answers: does the LayerNorm fold (operand rows fp16(x - mean), un-normalised; gains folded into row-centred weight
 images) lose anything against the plain mode (operand rows = the normalised LayerNorm output) when a few channels are 100 ...
-10^4 x the ordinary stream and the LayerNorm gains silence them?  It does, in proportion to the outliers' size: column j of a
-folded image holds gamma_j w_ij - c_i (c_i: the row's centring constant), so a channel with a tiny gain holds -c_i alone, and the
-fp16 rounding of x_j and of c_i is multiplied by the large x_j; the plain mode rounds gamma_j (x_j - mean) rstd and never sees
-it.  (--balanced: two outliers up, two down — the same result, so the common offset of the ordinary channels that the unbalanced
-set adds is not the cause; an un-centred image + a mean correction in the consumers' epilogues would remove the effect — oracle
-experiment, fold floor = plain floor up to 20000 x — at one more FMA per element and two more operands in the epilogues of the
-q/k, v and fc1 kernels; not built.)  The engine sits on its form's floor in every line, and the package's default checks the
-gains and leaves the fold off for such checkpoints (esm_amd/esm2.py ln_fold_hazard)."""
+10^4 x the ordinary stream and the LayerNorm gains silence them?  It does, in proportion to the outliers' size, through two
+terms (separated on the CPU with variants of the oracle's fold form, not kept in the tree):
+  (1) column j of a folded image holds gamma_j w_ij - c_i (c_i: the row's centring constant), so a channel with a tiny gain holds
+      -c_i alone, and the fp16 rounding of x_j and of c_i is multiplied by the large x_j.  With two outliers up and two down
+      (--balanced) this is the whole effect: an UN-CENTRED image + the mean correction - rstd (mean - centre) sum_j w'_ij in the
+      consumers' epilogues brings the fold's floor back onto the plain one (7.8e-4 / 1.05e-3 at 2000 x, 7.8e-4 / 1.13e-3 at
+      20000 x) — one more FMA per element and two more operands in the q/k, v and fc1 epilogues; not built;
+  (2) same-signed outliers (the default set: three up, one down) also move the row mean, i.e. give every ordinary channel the
+      same offset, and the LayerNorm bias takes it back: in the plain mode that happens BEFORE the rounding and the product with
+      the rounded weights, in the fold the bias enters exactly (fp32 W . beta) while its counterpart goes through the rounded
+      image — with (1) removed the fold's floor is still 2.8e-3 / 3.9e-3 at 2000 x; a robust centre (median of the slab means)
+      does not change that.  This one is the fold's form itself.
+The plain mode rounds gamma_j (x_j - mean) rstd + beta_j and sees neither.  The engine sits on its form's floor in every line,
+and the package's default checks the gains and leaves the fold off for such checkpoints (esm_amd/esm2.py ln_fold_hazard)."""
 import argparse
 import os
 import sys
