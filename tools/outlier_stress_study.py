@@ -17,7 +17,8 @@ terms (separated on the CPU with variants of the oracle's fold form, not kept in
       same offset, and the LayerNorm bias takes it back: in the plain mode that happens BEFORE the rounding and the product with
       the rounded weights, in the fold the bias enters exactly (fp32 W . beta) while its counterpart goes through the rounded
       image — with (1) removed the fold's floor is still 2.8e-3 / 3.9e-3 at 2000 x; a robust centre (median of the slab means)
-      does not change that.  This one is the fold's form itself.
+      does not change that; taking the bias through the same rounded image (sum_j w'_ij beta_j / gamma_j, pack time) does:
+      9.0e-4 / 1.4e-3 at 2000 x, 3.9e-3 / 5.1e-3 at 20000 x (what remains is the rounding of the offset rows themselves).
 The plain mode rounds gamma_j (x_j - mean) rstd + beta_j and sees neither.  The engine sits on its form's floor in every line,
 and the package's default checks the gains and leaves the fold off for such checkpoints (esm_amd/esm2.py ln_fold_hazard)."""
 import argparse
